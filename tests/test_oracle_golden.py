@@ -1,0 +1,81 @@
+"""Pins the CPU oracle (oracle/) against the committed golden fixtures: outputs of the
+reference's own source (TopoNet, BilinearSampler, get_patch_info_one_img, nms_points —
+extracted by AST in tests/golden/make_golden.py) and of the independent HF SAM encoder."""
+import numpy as np
+import torch
+
+from conftest import load_golden_module
+from oracle.samroad import AttrDict, BilinearSampler, TopoNet
+from oracle.sam_encoder import ImageEncoderViT
+from oracle import scene
+
+
+def test_toponet_and_sampler_match_reference_source(golden_dir):
+    g = np.load(f"{golden_dir}/toponet_sampler.npz")
+    mg = load_golden_module()
+    cfg = AttrDict(PATCH_SIZE=512, TOPONET_VERSION="normal")
+    topo = TopoNet(cfg, 256).eval()
+    topo.load_state_dict(mg.topo_weights(topo.state_dict()), strict=True)
+    feats = mg.topo_feats()
+    points, pairs, valid = (torch.tensor(g[k]) for k in ("points", "pairs", "valid"))
+    with torch.no_grad():
+        sampled = BilinearSampler(cfg)(feats, points)
+        logits, scores = topo(points, sampled, pairs, valid)
+    np.testing.assert_allclose(sampled.numpy(), g["sampled"], atol=1e-6)
+    v = valid.numpy().astype(bool)
+    np.testing.assert_allclose(logits.numpy()[..., 0][v], g["logits"][..., 0][v], atol=2e-5)
+    np.testing.assert_allclose(scores.numpy()[..., 0][v], g["scores"][..., 0][v], atol=1e-5)
+
+
+def test_patch_info_matches_reference_source(golden_dir):
+    g = np.load(f"{golden_dir}/patch_info.npz")
+    i = 0
+    while f"case{i}" in g:
+        info = scene.get_patch_info_one_img(0, *[int(v) for v in g[f"case{i}"]])
+        got = np.array([[p[1][0], p[1][1], p[2][0], p[2][1]] for p in info])
+        np.testing.assert_array_equal(got, g[f"xy{i}"])
+        i += 1
+    assert i == 7
+
+
+def test_nms_points_matches_reference_source(golden_dir):
+    g = np.load(f"{golden_dir}/nms_points.npz")
+    for i in range(4):
+        kept = scene.nms_points(g[f"pts{i}"], g[f"sc{i}"], int(g[f"r{i}"]))
+        np.testing.assert_array_equal(kept, g[f"kept{i}"])
+    np.testing.assert_array_equal(scene.nms_points(g["pts_p"], g["sc_p"], 16), g["kept_p"])
+
+
+def test_encoder_matches_hf_golden(golden_dir):
+    """Oracle encoder restatement vs the stored output of transformers' SamVisionEncoder."""
+    mg = load_golden_module()
+    y_ref = np.load(f"{golden_dir}/encoder_hf.npz")["y"]
+    enc = ImageEncoderViT(img_size=256, embed_dim=128, depth=3, num_heads=2, global_attn_indexes=[1]).eval()
+
+    def ren(k):
+        for a, b in (("layers.", "blocks."), ("layer_norm1", "norm1"), ("layer_norm2", "norm2"),
+                     ("patch_embed.projection", "patch_embed.proj"), ("neck.conv1", "neck.0"),
+                     ("neck.norm1", "neck.1"), ("neck.conv2", "neck.2"), ("neck.norm2", "neck.3")):
+            k = k.replace(a, b)
+        return k
+    # regenerate HF-ordered weights from the frozen stream, rename to the fork's keys
+    from transformers.models.sam.modeling_sam import SamVisionEncoder
+    hf_sd = mg.hf_small_weights(SamVisionEncoder(mg.hf_small_config()).state_dict())
+    enc.load_state_dict({ren(k): v for k, v in hf_sd.items()}, strict=True)
+    x = torch.tensor(np.random.RandomState(22).randn(1, 3, 256, 256).astype(np.float32))
+    with torch.no_grad():
+        y = enc(x)
+    np.testing.assert_allclose(y.numpy(), y_ref, atol=2e-4, rtol=1e-4)
+
+
+def test_torch_kats(golden_dir):
+    g = np.load(f"{golden_dir}/torch_kats.npz")
+    a = torch.arange(1024, dtype=torch.float32).view(1, 1, 32, 32)
+    cfg = AttrDict(PATCH_SIZE=512)
+    out = BilinearSampler(cfg)(a, torch.tensor(g["grid_px"]))
+    np.testing.assert_allclose(out.flatten().numpy(), g["grid_out"], atol=1e-6)
+    np.testing.assert_allclose(g["grid_out"], [0, 0, 0.46875, 0.5, 17.4375], atol=1e-6)
+    assert int(g["nan_u8"][0]) == 0
+    # dtype promotions the reference relies on
+    assert (torch.tensor([3], dtype=torch.int64) / 512).dtype == torch.float32
+    assert torch.concat([torch.zeros(1), torch.zeros(1), torch.zeros(1, dtype=torch.int64)]).dtype == torch.float32

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Headline benchmark: 512x512 ViT-B tiles/sec through SAMRoad.infer_masks_and_img_features.
+
+Workload = BASELINE.json configs[1]: toponet_vitb_512_cityscale.yaml, batch of 16 tiles of 512x512,
+ViT-B encoder + mask decoder, synthetic tiles and seeded random weights of that architecture.
+One "step" = one batch of 16 tiles per GPU, inputs already resident in HBM (f32 [16,512,512,3], what
+the reference hands to the model, inferencer.py:94).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: tiles are independent (pass 1 of infer_one_img shards embarrassingly), so every
+rank runs its own batches — weak scaling, no data-path collective; weights are broadcast from rank 0
+over RCCL before the timed region.  Prints ONE JSON line on rank 0.
+
+The line also carries
+  roofline      — the dominant kernel (the f16 MFMA GEMM, gemm.hip): algorithmic FLOPs of its launches
+                  / their summed duration, measured with HIP events on the launch stream in an
+                  instrumented pass of the same steps (events around every launch would perturb the
+                  headline timing, so they are a separate pass over the same work);
+  cpu_baseline  — the CPU oracle (oracle/, plain PyTorch fp32 eager = the reference's op sequence)
+                  timed on this host's cores on a bounded sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_TILE = 196.18          # algorithmic, ViT-B 512^2 encoder 195.34 + map_decoder 0.84
+MFMA_PEAK_TFLOPS = 2500.0        # MI355X dense f16/bf16 (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per step per GPU (BASELINE config 2: 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    warnings.simplefilter("ignore")
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from sam_road_amd import Config, SAMRoad
+    from sam_road_amd import _lib
+    from sam_road_amd.distributed import broadcast_state_dict
+
+    cfg = Config(SAM_VERSION="vit_b", PATCH_SIZE=512, TOPONET_VERSION="normal", SAM_CKPT_PATH="",
+                 NO_SAM=False, USE_SAM_DECODER=False, ENCODER_LORA=False)
+    net = SAMRoad(cfg)
+    # seeded random-init weights of the named architecture (no checkpoint exists offline)
+    g = torch.Generator().manual_seed(1234)
+    sd = {}
+    for k, v in net.state_dict().items():
+        if rank == 0:
+            if v.dim() == 1 and k.endswith("weight"):
+                t = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+            else:
+                t = 0.02 * torch.randn(v.shape, generator=g)
+        else:
+            t = torch.empty(v.shape)
+        sd[k] = t
+    if distributed:
+        sd = broadcast_state_dict(sd, src=0, device=dev)   # RCCL broadcast over xGMI
+    net.load_state_dict(sd, strict=True)
+    net.eval().to(dev)
+
+    B = args.batch
+    gi = torch.Generator().manual_seed(100 + rank)
+    rgb = (torch.rand((B, 512, 512, 3), generator=gi) * 255).round().to(dev)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        net.infer_masks_and_img_features(rgb)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scores, emb = net.infer_masks_and_img_features(rgb)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(scores).all() and torch.isfinite(emb).all()
+    tiles_per_s = world * B * args.steps / elapsed
+
+    out = {
+        "metric": "tiles/sec (512x512 ViT-B, SAMRoad.infer_masks_and_img_features: encoder + mask decoder)",
+        "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "toponet_vitb_512_cityscale.yaml, batch=16 512x512 tiles per GPU, ViT-B encoder "
+                               "+ map_decoder (BASELINE configs[1])",
+                   "tiles_per_step_per_gpu": B, "patch": 512, "input": "f32 NHWC resident in HBM",
+                   "weights": "seeded random init", "parallelism": f"tile-dp{world}",
+                   "gflop_per_tile_algorithmic": GFLOP_PER_TILE,
+                   "whole_path_mfma_frac": round(tiles_per_s / world * GFLOP_PER_TILE / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        ctx = _lib.Context.get(local_rank)
+        ctx.profile_enable(True)
+        for _ in range(max(1, min(args.steps, 5))):
+            net.infer_masks_and_img_features(rgb)
+        rows = ctx.profile_read()
+        ctx.profile_enable(False)
+        gemm = [r for r in rows if r["name"].startswith("gemm_")]
+        fl = sum(r["flops"] for r in gemm)
+        ms = sum(r["ms"] for r in gemm)
+        n = sum(r["launches"] for r in gemm)
+        total_ms = sum(r["ms"] for r in rows)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "srh::gemm_kernel<0> (f16 MFMA GEMM, all linear layers)",
+                           "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
+                           "share_of_gpu_time": round(ms / total_ms, 4) if total_ms else None,
+                           "by_class_ms_per_step": {r["name"]: round(r["ms"] / max(1, min(args.steps, 5)), 4) for r in rows}}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded CPU sample: the oracle (reference op sequence, eager fp32) on 2 tiles, 1 warm-up + 3 timed
+        from oracle.samroad import AttrDict, SAMRoadOracle
+        oracle = SAMRoadOracle(AttrDict(cfg)).eval()
+        oracle.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
+        x = rgb[:2].cpu()
+        oracle.infer_masks_and_img_features(x)
+        t0 = time.perf_counter()
+        iters = 3
+        for _ in range(iters):
+            oracle.infer_masks_and_img_features(x)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(2 * iters / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"oracle (plain PyTorch fp32 eager) infer_masks_and_img_features "
+                                                         f"on 2 of the {B} tiles, 1 warm-up + {iters} timed iterations"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

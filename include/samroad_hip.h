@@ -1,0 +1,143 @@
+/*
+ * samroad_hip.h — C ABI of libsamroad_hip.so: the MI355X (gfx950) implementation of sam_road's
+ * tiled-inference hot path.  Plain C types only (no torch, no C++ in the signatures).
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference has no FFI of its own for this
+ * path (it is pure Python on torch.nn); each entry point below names the reference interface it
+ * replaces (file:line under the reference repository) and INTEGRATION.md shows the ctypes binding a
+ * sam_road maintainer would add behind `SAMRoad`.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative srh_status; srh_last_error(ctx) has text;
+ *   - all data pointers are DEVICE pointers on the ctx's device unless documented as host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on
+ *     that stream; nothing is retained past return except by srh_weights_pack (which copies);
+ *   - the callee allocates nothing in hot calls except growing the ctx-owned workspace the first
+ *     time a larger batch is seen;
+ *   - image embeddings cross this ABI CHANNELS-LAST: [B, h, w, 256] f32 (the Python shim returns a
+ *     permuted view with the reference's logical shape [B, 256, h, w]).
+ */
+#ifndef SAMROAD_HIP_H
+#define SAMROAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRH_ABI_VERSION 1
+
+typedef enum {
+    SRH_OK = 0,
+    SRH_ERR_BAD_ARG = -1,      /* null pointer, bad dtype code, bad shape */
+    SRH_ERR_UNSUPPORTED = -2,  /* configuration not built (e.g. head_dim 80, USE_SAM_DECODER) */
+    SRH_ERR_HIP = -3,          /* HIP runtime error (text in srh_last_error) */
+    SRH_ERR_MISSING_WEIGHT = -4,
+    SRH_ERR_NO_DEVICE = -5
+} srh_status;
+
+typedef enum { SRH_F32 = 0, SRH_F16 = 1, SRH_U8 = 2, SRH_I32 = 3, SRH_I64 = 4 } srh_dtype;
+
+typedef struct srh_ctx srh_ctx;          /* per (process, device): workspace + error state */
+typedef struct srh_weights srh_weights;  /* packed, device-resident, immutable model weights */
+
+/* Architecture, mirrors SAMRoad.__init__ (model.py:197-258, :283-300). */
+typedef struct {
+    int32_t embed_dim;          /* 768 / 1024 / 1280 */
+    int32_t depth;              /* 12 / 24 / 32 */
+    int32_t num_heads;          /* 12 / 16 / 16 */
+    int32_t patch_size;         /* config.PATCH_SIZE: tile side in pixels (256 / 512) */
+    int32_t n_global;           /* number of entries used in global_attn_indexes */
+    int32_t global_attn_indexes[8];
+    int32_t window_size;        /* 14 */
+    int32_t toponet_version;    /* 0 'normal' (and 'no_tgt_features', App. D.7), 1 'no_offset', 2 'no_transformer' */
+} srh_model_cfg;
+
+/* One state_dict entry (SURVEY.md Appendix A names), f32, contiguous. */
+typedef struct {
+    const char* name;
+    const void* data;           /* host pointer, or device pointer if on_device != 0 */
+    int32_t on_device;
+    int32_t ndim;
+    int64_t shape[4];
+} srh_named_tensor;
+
+int srh_abi_version(void);
+
+/* lifetime ------------------------------------------------------------------------------------ */
+int srh_ctx_create(int device, srh_ctx** out);
+void srh_ctx_destroy(srh_ctx* ctx);
+const char* srh_last_error(const srh_ctx* ctx);
+
+/* Packs `net.load_state_dict(ckpt["state_dict"])` + `net.to(device)` (inferencer.py:250-254):
+ * fp16 MFMA operand copies of every matmul weight (conv kernels re-ordered to the GEMM K order),
+ * f32 biases / LayerNorm affine / pos_embed, fp16 rel_pos tables. */
+int srh_weights_pack(srh_ctx* ctx, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
+                     srh_weights** out);
+void srh_weights_free(srh_weights* w);
+
+/* model ----------------------------------------------------------------------------------------- */
+
+/* SAMRoad.infer_masks_and_img_features (model.py:459-495; body shared with forward :420-446):
+ * rgb [B,P,P,3] channels-last, values 0..255, dtype SRH_F32 or SRH_U8
+ *   -> mask_logits (nullable) / mask_scores (nullable) [B,P,P,2] f32, embeddings [B,h,w,256] f32. */
+int srh_encode_decode(srh_ctx* ctx, const srh_weights* w, const void* rgb, int rgb_dtype, int B,
+                      float* mask_logits, float* mask_scores, float* embeddings, void* stream);
+
+/* SAMRoad.infer_toponet (model.py:498-508) = BilinearSampler (:29-58) + TopoNet (:61-148).
+ * embeddings [B,h,w,256] f32 channels-last; points [B,N,2] (x,y) SRH_I64 or SRH_F32;
+ * pairs [B,Ns,K,2] SRH_I64 or SRH_I32; valid [B,Ns,K] u8 (bool); K must be 16.
+ *   -> logits (nullable) / scores (nullable) [B,Ns,K] f32. */
+int srh_toponet(srh_ctx* ctx, const srh_weights* w, const float* embeddings, const void* points,
+                int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
+                int Ns, int K, float* logits, float* scores, void* stream);
+
+/* scene level (pass 1 of infer_one_img, inferencer.py:79-110) ------------------------------------ */
+
+/* Tile batcher + model + mask fusion: crops n_tiles PxP tiles at tile_xy[(x0,y0)] (device int32)
+ * out of a resident u8 scene [S,S,3], runs them in batches of B, accumulates mask scores into the
+ * two f32 canvases [S,S] (caller zero-initialises) in the reference's sequential tile order, and
+ * writes every tile's embeddings to embeddings_all [n_tiles,h,w,256]. */
+int srh_scene_pass1(srh_ctx* ctx, const srh_weights* w, const uint8_t* scene, int S, const int32_t* tile_xy,
+                    int n_tiles, int B, float* canvas_kp, float* canvas_road, float* embeddings_all,
+                    void* stream);
+
+/* canvas / coverage-count * 255 -> u8 (truncation; uncovered border -> 0), inferencer.py:106-110. */
+int srh_scene_normalise(srh_ctx* ctx, const float* canvas_kp, const float* canvas_road, int S,
+                        const int32_t* tile_xy, int n_tiles, int P, uint8_t* kp_u8, uint8_t* road_u8,
+                        void* stream);
+
+/* op level (used by the parity tests to localise a failure; same kernels as above) ----------------- */
+
+/* out = act(A[M,K] W[N,K]^T + bias) (+resid); A,W fp16; N%128==0, K%64==0. act: 0/1 GELU/2 ReLU. */
+int srh_op_gemm(srh_ctx* ctx, const void* A_f16, const void* W_f16, const float* bias, const float* resid,
+                int M, int N, int K, int act, float* out_f32, void* out_f16, void* stream);
+/* 3x3 pad-1 conv over channels-last [B,S,S,C] as implicit GEMM; W_f16 [N, 9*C] (k = tap*C + c). */
+int srh_op_conv3x3(srh_ctx* ctx, const void* A_f16, const void* W_f16, int B, int S, int C, int N,
+                   float* out_f32, void* stream);
+int srh_op_layernorm(srh_ctx* ctx, const float* x, const float* gamma, const float* beta, float eps, int M,
+                     int D, int gelu, float* out_f32, void* out_f16, void* stream);
+/* SAM attention on a fused qkv tensor [B*S*S, 3*heads*64] fp16: rel-pos tables [2*win-1, 64] fp16,
+ * qkv bias fp16 [3*heads*64] (pad-key rows), win = 14 (windowed) or S (global). out fp16 [B*S*S, heads*64]. */
+int srh_op_attention(srh_ctx* ctx, const void* qkv_f16, const void* relpos_h_f16, const void* relpos_w_f16,
+                     const void* bias_qkv_f16, int B, int S, int heads, int win, void* out_f16, void* stream);
+
+/* profiling --------------------------------------------------------------------------------------- */
+
+/* When enabled, every kernel launch made by this ctx is bracketed by HIP events on the launch
+ * stream.  srh_profile_read synchronises, then returns per-class totals since the last enable. */
+typedef struct {
+    char name[32];
+    int64_t launches;
+    double ms;          /* summed GPU time of the launches */
+    double flops;       /* algorithmic FLOPs (2*M*N*K for GEMMs; q.k + p.v for attention), else 0 */
+    double bytes;       /* algorithmic HBM bytes for bandwidth-bound classes, else 0 */
+} srh_profile_row;
+int srh_profile_enable(srh_ctx* ctx, int on);
+int srh_profile_read(srh_ctx* ctx, srh_profile_row* rows, int max_rows, int* n_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMROAD_HIP_H */

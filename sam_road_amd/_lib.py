@@ -1,0 +1,112 @@
+"""ctypes binding of libsamroad_hip.so (C ABI: include/samroad_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  Nothing here imports ``oracle/``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsamroad_hip.so")
+
+SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
+
+
+class SrhError(RuntimeError):
+    pass
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
+                ("patch_size", C.c_int32), ("n_global", C.c_int32), ("global_attn_indexes", C.c_int32 * 8),
+                ("window_size", C.c_int32), ("toponet_version", C.c_int32)]
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("on_device", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+class ProfileRow(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+# every symbol include/samroad_hip.h declares: (restype, argtypes)
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+SYMBOLS = {
+    "srh_abi_version": (_I, []),
+    "srh_ctx_create": (_I, [_I, C.POINTER(_P)]),
+    "srh_ctx_destroy": (None, [_P]),
+    "srh_last_error": (C.c_char_p, [_P]),
+    "srh_weights_pack": (_I, [_P, C.POINTER(ModelCfg), C.POINTER(NamedTensor), _I, C.POINTER(_P)]),
+    "srh_weights_free": (None, [_P]),
+    "srh_encode_decode": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "srh_toponet": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "srh_scene_pass1": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "srh_scene_normalise": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "srh_op_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "srh_op_conv3x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "srh_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
+    "srh_op_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "srh_profile_enable": (_I, [_P, _I]),
+    "srh_profile_read": (_I, [_P, C.POINTER(ProfileRow), _I, C.POINTER(_I)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built — no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrhError(f"{LIB_PATH} not found: build it with `python -m sam_road_amd.build` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.srh_abi_version() != 1:
+        raise SrhError("libsamroad_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One per (process, device)."""
+    _by_device = {}
+
+    def __init__(self, device_index):
+        self.lib = load()
+        h = _P()
+        rc = self.lib.srh_ctx_create(int(device_index), C.byref(h))
+        if rc != 0:
+            raise SrhError(f"srh_ctx_create(device={device_index}) failed with status {rc} "
+                           "(no MI355X visible? there is no CPU fallback)")
+        self.handle = h
+        self.device_index = int(device_index)
+
+    @classmethod
+    def get(cls, device_index):
+        ctx = cls._by_device.get(device_index)
+        if ctx is None:
+            ctx = cls._by_device[device_index] = Context(device_index)
+        return ctx
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.srh_last_error(self.handle)
+            raise SrhError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.srh_profile_enable(self.handle, 1 if on else 0), "srh_profile_enable")
+
+    def profile_read(self):
+        rows = (ProfileRow * 64)()
+        n = _I(0)
+        self.check(self.lib.srh_profile_read(self.handle, rows, 64, C.byref(n)), "srh_profile_read")
+        return [dict(name=rows[i].name.decode(), launches=rows[i].launches, ms=rows[i].ms,
+                     flops=rows[i].flops, bytes=rows[i].bytes) for i in range(n.value)]

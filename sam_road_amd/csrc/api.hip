@@ -1,0 +1,693 @@
+// C ABI of libsamroad_hip.so (declared in include/samroad_hip.h): context / workspace, weight
+// packing, and the launch sequences for SAMRoad.infer_masks_and_img_features, infer_toponet and
+// the scene-level pass 1 of infer_one_img.  Host-side C++ only; all arithmetic is in the .hip kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/samroad_hip.h"
+#include "kernels.hpp"
+
+using namespace srh;
+
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) return SRH_ERR_HIP;
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfEntry { int cls; hipEvent_t e0, e1; double flops, bytes; };
+
+struct srh_ctx {
+    int device = 0;
+    std::string err;
+    // encoder / decoder workspace
+    DevBuf a0, x, xn16, qkv16, rel, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16, d2_16;
+    DevBuf scores_ws, emb_ws, counter;
+    // toponet workspace
+    DevBuf t_feat16, t_pf16, t_pair16, t_x, t_x16, t_qkv16, t_at16, t_y, t_h16;
+    // profiling
+    bool profiling = false;
+    std::vector<std::string> cls_names;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+struct BlockW {
+    int win = 0;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    f16 *qkv_w, *qkv_b16, *rel_h, *rel_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct TopoLayerW {
+    f16 *in_w, *out_w, *l1_w, *l2_w;
+    float *in_b, *out_b, *l1_b, *l2_b, *n1_g, *n1_b, *n2_g, *n2_b;
+};
+struct srh_weights {
+    srh_model_cfg cfg;
+    int S = 0, D = 0, heads = 0, hd = 0;
+    void* arena = nullptr;
+    f16* patch_w; float* patch_b; float* pos;
+    std::vector<BlockW> blocks;
+    f16 *neck0_w, *neck2_w; float *neck1_g, *neck1_b, *neck3_g, *neck3_b;
+    f16 *dec0_w, *dec3_w, *dec5_w; float *dec0_b, *dec1_g, *dec1_b, *dec3_b, *dec5_b, *dec7_w, *dec7_b;
+    f16 *tp_feat_w, *tp_pair_w; float *tp_feat_b, *tp_pair_b, *tp_out_w, *tp_out_b;
+    std::vector<TopoLayerW> tlayers;
+};
+
+static int fail(srh_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+static int hip_fail(srh_ctx* c, hipError_t e, const char* where) {
+    return fail(c, SRH_ERR_HIP, std::string(where) + ": " + hipGetErrorString(e));
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+static int cls_id(srh_ctx* c, const char* name) {
+    for (size_t i = 0; i < c->cls_names.size(); ++i)
+        if (c->cls_names[i] == name) return (int)i;
+    c->cls_names.push_back(name);
+    return (int)c->cls_names.size() - 1;
+}
+static hipEvent_t next_event(srh_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+template <class F>
+static int run(srh_ctx* c, const char* cls, double flops, double bytes, hipStream_t s, F&& f) {
+    if (!c->profiling) return f();
+    ProfEntry pe;
+    pe.cls = cls_id(c, cls);
+    pe.flops = flops; pe.bytes = bytes;
+    pe.e0 = next_event(c);
+    pe.e1 = next_event(c);
+    hipEventRecord(pe.e0, s);
+    const int rc = f();
+    hipEventRecord(pe.e1, s);
+    c->prof.push_back(pe);
+    return rc;
+}
+
+static int gemm(srh_ctx* c, const char* cls, const GemmParams& p, hipStream_t s) {
+    const double fl = 2.0 * p.M * (double)p.N * p.K;
+    const int rc = run(c, cls, fl, 0.0, s, [&] { return launch_gemm(p, s); });
+    if (rc) return fail(c, rc == -2 ? SRH_ERR_UNSUPPORTED : SRH_ERR_HIP, std::string("gemm ") + cls + " launch failed");
+    return 0;
+}
+
+// ---- C ABI: lifetime -----------------------------------------------------------------------------
+extern "C" int srh_abi_version(void) { return SRH_ABI_VERSION; }
+
+extern "C" int srh_ctx_create(int device, srh_ctx** out) {
+    if (!out) return SRH_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SRH_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SRH_ERR_HIP;
+    srh_ctx* c = new srh_ctx();
+    c->device = device;
+    *out = c;
+    return SRH_OK;
+}
+
+extern "C" void srh_ctx_destroy(srh_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->qkv16, &c->rel, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
+                      &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->d2_16, &c->scores_ws, &c->emb_ws, &c->counter,
+                      &c->t_feat16, &c->t_pf16, &c->t_pair16, &c->t_x, &c->t_x16, &c->t_qkv16, &c->t_at16, &c->t_y, &c->t_h16};
+    for (DevBuf* b : bufs) b->release();
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" const char* srh_last_error(const srh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+// ---- weight packing --------------------------------------------------------------------------------
+namespace {
+struct Packer {
+    srh_ctx* c;
+    std::map<std::string, const srh_named_tensor*> by_name;
+    std::vector<char> host;                       // staging image of the device arena
+    std::vector<std::pair<void**, size_t>> fix;   // pointer slots to patch with arena + offset
+    std::vector<float> tmp;
+    std::string missing;
+
+    size_t alloc(size_t bytes) {
+        const size_t off = (host.size() + 255) & ~size_t(255);
+        host.resize(off + bytes);
+        return off;
+    }
+    // fetch tensor as host f32 (copying from device if needed); checks element count
+    const float* get(const std::string& name, size_t expect) {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) { if (missing.empty()) missing = name; return nullptr; }
+        const srh_named_tensor* t = it->second;
+        size_t n = 1;
+        for (int i = 0; i < t->ndim; ++i) n *= (size_t)t->shape[i];
+        if (n != expect) { if (missing.empty()) missing = name + " (shape mismatch)"; return nullptr; }
+        if (!t->on_device) return reinterpret_cast<const float*>(t->data);
+        tmp.resize(n);
+        if (hipMemcpy(tmp.data(), t->data, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (missing.empty()) missing = name + " (D2H copy failed)";
+            return nullptr;
+        }
+        return tmp.data();
+    }
+    template <class T> void slot(T** dst, size_t off) { fix.push_back({reinterpret_cast<void**>(dst), off}); }
+
+    void put_f32(float** dst, const std::string& name, size_t n) {
+        const float* src = get(name, n);
+        const size_t off = alloc(n * 4);
+        if (src) memcpy(host.data() + off, src, n * 4);
+        slot(dst, off);
+    }
+    // fp16 copy with an index map: out[i] = src[map(i)]
+    template <class Map>
+    void put_f16(f16** dst, const std::string& name, size_t n_src, size_t n_out, Map map) {
+        const float* src = get(name, n_src);
+        const size_t off = alloc(n_out * 2);
+        if (src) {
+            f16* o = reinterpret_cast<f16*>(host.data() + off);
+            for (size_t i = 0; i < n_out; ++i) {
+                const long j = map(i);
+                o[i] = j < 0 ? (f16)0.f : (f16)src[j];
+            }
+        }
+        slot(dst, off);
+    }
+    void put_f16_same(f16** dst, const std::string& name, size_t n) {
+        put_f16(dst, name, n, n, [](size_t i) { return (long)i; });
+    }
+};
+}  // namespace
+
+extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
+                                srh_weights** out) {
+    if (!c || !cfg || !tensors || !out) return fail(c, SRH_ERR_BAD_ARG, "srh_weights_pack: null argument");
+    *out = nullptr;
+    const int D = cfg->embed_dim, heads = cfg->num_heads;
+    if (D <= 0 || heads <= 0 || D % heads) return fail(c, SRH_ERR_BAD_ARG, "bad embed_dim / num_heads");
+    const int hd = D / heads;
+    if (hd != 64) return fail(c, SRH_ERR_UNSUPPORTED, "head_dim != 64 (ViT-H) is not built yet");
+    if (cfg->patch_size % 16) return fail(c, SRH_ERR_BAD_ARG, "PATCH_SIZE must be a multiple of 16");
+    const int S = cfg->patch_size / 16;
+    if (S != 16 && S != 32) return fail(c, SRH_ERR_UNSUPPORTED, "PATCH_SIZE must be 256 or 512");
+    if (cfg->window_size != 14) return fail(c, SRH_ERR_UNSUPPORTED, "window_size must be 14");
+    if (D % 128 || (D != 768 && D != 1024)) return fail(c, SRH_ERR_UNSUPPORTED, "embed_dim must be 768 or 1024");
+    hipSetDevice(c->device);
+
+    srh_weights* w = new srh_weights();
+    w->cfg = *cfg; w->S = S; w->D = D; w->heads = heads; w->hd = hd;
+    Packer pk;
+    pk.c = c;
+    for (int i = 0; i < n; ++i) pk.by_name[tensors[i].name] = &tensors[i];
+    const std::string E = "image_encoder.";
+
+    pk.put_f16(&w->patch_w, E + "patch_embed.proj.weight", (size_t)D * 768, (size_t)D * 768, [](size_t i) {
+        const size_t nidx = i / 768, k = i % 768;
+        const size_t ky = k / 48, kx = (k % 48) / 3, ch = k % 3;
+        return (long)(nidx * 768 + ch * 256 + ky * 16 + kx);
+    });
+    pk.put_f32(&w->patch_b, E + "patch_embed.proj.bias", D);
+    pk.put_f32(&w->pos, E + "pos_embed", (size_t)S * S * D);
+
+    w->blocks.resize(cfg->depth);
+    for (int i = 0; i < cfg->depth; ++i) {
+        BlockW& b = w->blocks[i];
+        bool global = false;
+        for (int g = 0; g < cfg->n_global; ++g) global |= cfg->global_attn_indexes[g] == i;
+        b.win = global ? S : cfg->window_size;
+        const std::string B_ = E + "blocks." + std::to_string(i) + ".";
+        pk.put_f32(&b.ln1_g, B_ + "norm1.weight", D);
+        pk.put_f32(&b.ln1_b, B_ + "norm1.bias", D);
+        pk.put_f32(&b.ln2_g, B_ + "norm2.weight", D);
+        pk.put_f32(&b.ln2_b, B_ + "norm2.bias", D);
+        pk.put_f16_same(&b.qkv_w, B_ + "attn.qkv.weight", (size_t)3 * D * D);
+        pk.put_f32(&b.qkv_b, B_ + "attn.qkv.bias", (size_t)3 * D);
+        pk.put_f16_same(&b.qkv_b16, B_ + "attn.qkv.bias", (size_t)3 * D);
+        pk.put_f16_same(&b.rel_h, B_ + "attn.rel_pos_h", (size_t)(2 * b.win - 1) * hd);
+        pk.put_f16_same(&b.rel_w, B_ + "attn.rel_pos_w", (size_t)(2 * b.win - 1) * hd);
+        pk.put_f16_same(&b.proj_w, B_ + "attn.proj.weight", (size_t)D * D);
+        pk.put_f32(&b.proj_b, B_ + "attn.proj.bias", D);
+        pk.put_f16_same(&b.fc1_w, B_ + "mlp.lin1.weight", (size_t)4 * D * D);
+        pk.put_f32(&b.fc1_b, B_ + "mlp.lin1.bias", (size_t)4 * D);
+        pk.put_f16_same(&b.fc2_w, B_ + "mlp.lin2.weight", (size_t)4 * D * D);
+        pk.put_f32(&b.fc2_b, B_ + "mlp.lin2.bias", D);
+    }
+    pk.put_f16_same(&w->neck0_w, E + "neck.0.weight", (size_t)256 * D);
+    pk.put_f32(&w->neck1_g, E + "neck.1.weight", 256);
+    pk.put_f32(&w->neck1_b, E + "neck.1.bias", 256);
+    pk.put_f16(&w->neck2_w, E + "neck.2.weight", (size_t)256 * 256 * 9, (size_t)256 * 2304, [](size_t i) {
+        const size_t nidx = i / 2304, k = i % 2304, tap = k / 256, ch = k % 256;
+        return (long)((nidx * 256 + ch) * 9 + tap);
+    });
+    pk.put_f32(&w->neck3_g, E + "neck.3.weight", 256);
+    pk.put_f32(&w->neck3_b, E + "neck.3.bias", 256);
+
+    // map_decoder: ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM weight [n = (ky*2+kx)*Cout + co][ci]
+    auto convt = [&](f16** dst, float** bdst, const std::string& idx, int cin, int cout) {
+        pk.put_f16(dst, "map_decoder." + idx + ".weight", (size_t)cin * cout * 4, (size_t)4 * cout * cin,
+                   [cin, cout](size_t i) {
+                       const size_t nidx = i / cin, ci = i % cin, sub = nidx / cout, co = nidx % cout;
+                       return (long)((ci * cout + co) * 4 + sub);
+                   });
+        const float* bsrc = pk.get("map_decoder." + idx + ".bias", cout);
+        const size_t off = pk.alloc((size_t)4 * cout * 4);
+        if (bsrc)
+            for (int r = 0; r < 4; ++r) memcpy(pk.host.data() + off + (size_t)r * cout * 4, bsrc, (size_t)cout * 4);
+        pk.slot(bdst, off);
+    };
+    convt(&w->dec0_w, &w->dec0_b, "0", 256, 128);
+    pk.put_f32(&w->dec1_g, "map_decoder.1.weight", 128);
+    pk.put_f32(&w->dec1_b, "map_decoder.1.bias", 128);
+    convt(&w->dec3_w, &w->dec3_b, "3", 128, 64);
+    convt(&w->dec5_w, &w->dec5_b, "5", 64, 32);
+    {
+        const float* src = pk.get("map_decoder.7.weight", 32 * 2 * 4);
+        const size_t off = pk.alloc(8 * 32 * 4);
+        if (src) {
+            float* o = reinterpret_cast<float*>(pk.host.data() + off);
+            for (int nn = 0; nn < 8; ++nn)
+                for (int ci = 0; ci < 32; ++ci) o[nn * 32 + ci] = src[(ci * 2 + (nn & 1)) * 4 + (nn >> 1)];
+        }
+        pk.slot(&w->dec7_w, off);
+        pk.put_f32(&w->dec7_b, "map_decoder.7.bias", 2);
+    }
+
+    // TopoNet
+    const std::string T = "topo_net.";
+    pk.put_f16_same(&w->tp_feat_w, T + "feature_proj.weight", 128 * 256);
+    pk.put_f32(&w->tp_feat_b, T + "feature_proj.bias", 128);
+    pk.put_f16(&w->tp_pair_w, T + "pair_proj.weight", 128 * 258, 128 * 320, [](size_t i) {
+        const size_t nidx = i / 320, k = i % 320;
+        return k < 258 ? (long)(nidx * 258 + k) : -1L;
+    });
+    pk.put_f32(&w->tp_pair_b, T + "pair_proj.bias", 128);
+    if (cfg->toponet_version != 2) {
+        w->tlayers.resize(3);
+        for (int l = 0; l < 3; ++l) {
+            TopoLayerW& tl = w->tlayers[l];
+            const std::string L = T + "transformer_encoder.layers." + std::to_string(l) + ".";
+            pk.put_f16_same(&tl.in_w, L + "self_attn.in_proj_weight", 384 * 128);
+            pk.put_f32(&tl.in_b, L + "self_attn.in_proj_bias", 384);
+            pk.put_f16_same(&tl.out_w, L + "self_attn.out_proj.weight", 128 * 128);
+            pk.put_f32(&tl.out_b, L + "self_attn.out_proj.bias", 128);
+            pk.put_f16_same(&tl.l1_w, L + "linear1.weight", 128 * 128);
+            pk.put_f32(&tl.l1_b, L + "linear1.bias", 128);
+            pk.put_f16_same(&tl.l2_w, L + "linear2.weight", 128 * 128);
+            pk.put_f32(&tl.l2_b, L + "linear2.bias", 128);
+            pk.put_f32(&tl.n1_g, L + "norm1.weight", 128);
+            pk.put_f32(&tl.n1_b, L + "norm1.bias", 128);
+            pk.put_f32(&tl.n2_g, L + "norm2.weight", 128);
+            pk.put_f32(&tl.n2_b, L + "norm2.bias", 128);
+        }
+    }
+    pk.put_f32(&w->tp_out_w, T + "output_proj.weight", 128);
+    pk.put_f32(&w->tp_out_b, T + "output_proj.bias", 1);
+
+    if (!pk.missing.empty()) {
+        delete w;
+        return fail(c, SRH_ERR_MISSING_WEIGHT, "state_dict entry missing or mis-shaped: " + pk.missing);
+    }
+    hipError_t e = hipMalloc(&w->arena, pk.host.size());
+    if (e != hipSuccess) { delete w; return hip_fail(c, e, "hipMalloc(weights)"); }
+    e = hipMemcpy(w->arena, pk.host.data(), pk.host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(w->arena); delete w; return hip_fail(c, e, "hipMemcpy(weights)"); }
+    for (auto& f : pk.fix) *f.first = reinterpret_cast<char*>(w->arena) + f.second;
+    *out = w;
+    return SRH_OK;
+}
+
+extern "C" void srh_weights_free(srh_weights* w) {
+    if (!w) return;
+    if (w->arena) hipFree(w->arena);
+    delete w;
+}
+
+// ---- encoder + decoder -------------------------------------------------------------------------------
+static double attn_flops(int B, int S, int heads, int hd, int win) {
+    if (win == S) return 4.0 * B * heads * (double)S * S * S * S * hd;
+    const int nw = (S + win - 1) / win;
+    double q = 0;
+    for (int wy = 0; wy < nw; ++wy)
+        for (int wx = 0; wx < nw; ++wx)
+            q += (double)std::min(win, S - wy * win) * std::min(win, S - wx * win);
+    return 4.0 * B * heads * q * win * win * hd;
+}
+
+static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
+    const size_t T = (size_t)B * w->S * w->S, D = w->D;
+    int rc = 0;
+    rc |= c->a0.ensure(T * 768 * 2);
+    rc |= c->x.ensure(T * D * 4);
+    rc |= c->xn16.ensure(T * D * 2);
+    rc |= c->qkv16.ensure(T * 3 * D * 2);
+    rc |= c->rel.ensure(T * w->heads * 64 * 4);
+    rc |= c->attn16.ensure(T * D * 2);
+    rc |= c->hid16.ensure(T * 4 * D * 2);
+    rc |= c->n1.ensure(T * 256 * 4);
+    rc |= c->n1_16.ensure(T * 256 * 2);
+    rc |= c->n2.ensure(T * 256 * 4);
+    rc |= c->emb16.ensure(T * 256 * 2);
+    rc |= c->d0.ensure(T * 512 * 4);
+    rc |= c->d0_16.ensure(T * 512 * 2);
+    rc |= c->d1_16.ensure(T * 1024 * 2);
+    rc |= c->d2_16.ensure(T * 2048 * 2);
+    return rc ? fail(c, SRH_ERR_HIP, "workspace allocation failed") : 0;
+}
+
+#define TRY(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define TRYK(c, cls, fl, by, s, call) do { const int rc_ = run(c, cls, fl, by, s, [&] { return (call); }); \
+    if (rc_) return fail(c, rc_ == -2 ? SRH_ERR_UNSUPPORTED : SRH_ERR_HIP, std::string(cls) + ": kernel launch failed"); } while (0)
+
+static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B, float* logits, float* scores,
+                        float* emb, hipStream_t s) {
+    const int S = w->S, D = w->D, heads = w->heads, hd = w->hd;
+    const int T = B * S * S;
+    TRY(ensure_encoder_ws(c, w, B));
+    pp.B = B; pp.P = w->cfg.patch_size; pp.out = c->a0.as<f16>();
+    TRYK(c, "patch_im2col", 0, (double)T * 768 * (pp.src_is_u8 ? 3 : 6), s, launch_patch_im2col(pp, s));
+    {
+        GemmParams g;
+        g.A = c->a0.as<f16>(); g.lda = 768; g.W = w->patch_w; g.ldw = 768; g.M = T; g.N = D; g.K = 768;
+        g.bias = w->patch_b; g.pos = w->pos; g.pos_rows = S * S; g.out_f32 = c->x.as<float>(); g.ldc = D;
+        TRY(gemm(c, "gemm_patch_embed", g, s));
+    }
+    for (const BlockW& b : w->blocks) {
+        NormParams ln;
+        ln.x = c->x.as<float>(); ln.M = T; ln.D = D; ln.eps = 1e-6f; ln.out_f16 = c->xn16.as<f16>();
+        ln.gamma = b.ln1_g; ln.beta = b.ln1_b;
+        TRYK(c, "layernorm", 0, (double)T * D * 6, s, launch_layernorm(ln, s));
+        GemmParams g;
+        g.A = c->xn16.as<f16>(); g.lda = D; g.W = b.qkv_w; g.ldw = D; g.M = T; g.N = 3 * D; g.K = D;
+        g.bias = b.qkv_b; g.out_f16 = c->qkv16.as<f16>(); g.ldc16 = 3 * D;
+        TRY(gemm(c, "gemm_qkv", g, s));
+        RelPosParams rp;
+        rp.qkv = c->qkv16.as<f16>(); rp.ld = 3 * D; rp.table_h = b.rel_h; rp.table_w = b.rel_w;
+        rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = b.win;
+        rp.inv_scale = sqrtf((float)hd);
+        TRYK(c, b.win == S ? "relpos_global" : "relpos_window", 4.0 * T * heads * b.win * hd, 0, s, launch_relpos(rp, s));
+        AttnParams ap;
+        ap.qkv = c->qkv16.as<f16>(); ap.ld = 3 * D; ap.rel = c->rel.as<float>(); ap.bias_qkv = b.qkv_b16;
+        ap.out = c->attn16.as<f16>(); ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = b.win;
+        ap.scale = 1.0f / sqrtf((float)hd);
+        TRYK(c, b.win == S ? "attn_global" : "attn_window", attn_flops(B, S, heads, hd, b.win), 0, s, launch_attention(ap, s));
+        GemmParams gp;
+        gp.A = c->attn16.as<f16>(); gp.lda = D; gp.W = b.proj_w; gp.ldw = D; gp.M = T; gp.N = D; gp.K = D;
+        gp.bias = b.proj_b; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
+        TRY(gemm(c, "gemm_proj", gp, s));
+        ln.gamma = b.ln2_g; ln.beta = b.ln2_b;
+        TRYK(c, "layernorm", 0, (double)T * D * 6, s, launch_layernorm(ln, s));
+        GemmParams g1;
+        g1.A = c->xn16.as<f16>(); g1.lda = D; g1.W = b.fc1_w; g1.ldw = D; g1.M = T; g1.N = 4 * D; g1.K = D;
+        g1.bias = b.fc1_b; g1.act = 1; g1.out_f16 = c->hid16.as<f16>(); g1.ldc16 = 4 * D;
+        TRY(gemm(c, "gemm_fc1", g1, s));
+        GemmParams g2;
+        g2.A = c->hid16.as<f16>(); g2.lda = 4 * D; g2.W = b.fc2_w; g2.ldw = 4 * D; g2.M = T; g2.N = D; g2.K = 4 * D;
+        g2.bias = b.fc2_b; g2.resid = c->x.as<float>(); g2.ldr = D; g2.out_f32 = c->x.as<float>(); g2.ldc = D;
+        TRY(gemm(c, "gemm_fc2", g2, s));
+    }
+    // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d  (channels-last: LN2d is a row LN)
+    {
+        NormParams cast;
+        cast.x = c->x.as<float>(); cast.M = T; cast.D = D; cast.out_f16 = c->xn16.as<f16>();
+        TRYK(c, "layernorm", 0, (double)T * D * 6, s, launch_layernorm(cast, s));
+        GemmParams g;
+        g.A = c->xn16.as<f16>(); g.lda = D; g.W = w->neck0_w; g.ldw = D; g.M = T; g.N = 256; g.K = D;
+        g.out_f32 = c->n1.as<float>(); g.ldc = 256;
+        TRY(gemm(c, "gemm_neck", g, s));
+        NormParams ln;
+        ln.x = c->n1.as<float>(); ln.M = T; ln.D = 256; ln.eps = 1e-6f; ln.gamma = w->neck1_g; ln.beta = w->neck1_b;
+        ln.out_f16 = c->n1_16.as<f16>();
+        TRYK(c, "layernorm", 0, (double)T * 256 * 6, s, launch_layernorm(ln, s));
+        GemmParams g3;
+        g3.A = c->n1_16.as<f16>(); g3.lda = 256; g3.W = w->neck2_w; g3.ldw = 2304; g3.M = T; g3.N = 256; g3.K = 2304;
+        g3.conv_S = S; g3.conv_C = 256; g3.out_f32 = c->n2.as<float>(); g3.ldc = 256;
+        TRY(gemm(c, "gemm_neck", g3, s));
+        ln.x = c->n2.as<float>(); ln.gamma = w->neck3_g; ln.beta = w->neck3_b;
+        ln.out_f16 = c->emb16.as<f16>(); ln.out_f32 = emb;
+        TRYK(c, "layernorm", 0, (double)T * 256 * 10, s, launch_layernorm(ln, s));
+    }
+    if (!logits && !scores) return 0;
+    // map_decoder: 3 per-pixel GEMMs (ConvT k2 s2) + LN2d/GELU, then the fused 32->2 tail
+    {
+        GemmParams g;
+        g.A = c->emb16.as<f16>(); g.lda = 256; g.W = w->dec0_w; g.ldw = 256; g.M = T; g.N = 512; g.K = 256;
+        g.bias = w->dec0_b; g.out_f32 = c->d0.as<float>(); g.ldc = 512;
+        TRY(gemm(c, "gemm_decoder", g, s));
+        NormParams ln;
+        ln.x = c->d0.as<float>(); ln.M = 4 * T; ln.D = 128; ln.eps = 1e-6f; ln.gamma = w->dec1_g; ln.beta = w->dec1_b;
+        ln.act = 1; ln.out_f16 = c->d0_16.as<f16>();
+        TRYK(c, "layernorm", 0, (double)T * 512 * 6, s, launch_layernorm(ln, s));
+        GemmParams g1;
+        g1.A = c->d0_16.as<f16>(); g1.lda = 128; g1.W = w->dec3_w; g1.ldw = 128; g1.M = 4 * T; g1.N = 256; g1.K = 128;
+        g1.bias = w->dec3_b; g1.act = 1; g1.out_f16 = c->d1_16.as<f16>(); g1.ldc16 = 256;
+        TRY(gemm(c, "gemm_decoder", g1, s));
+        GemmParams g2;
+        g2.A = c->d1_16.as<f16>(); g2.lda = 64; g2.W = w->dec5_w; g2.ldw = 64; g2.M = 16 * T; g2.N = 128; g2.K = 64;
+        g2.bias = w->dec5_b; g2.act = 1; g2.out_f16 = c->d2_16.as<f16>(); g2.ldc16 = 128;
+        TRY(gemm(c, "gemm_decoder", g2, s));
+        DecodeOutParams dp;
+        dp.x = c->d2_16.as<f16>(); dp.w = w->dec7_w; dp.bias = w->dec7_b; dp.B = B; dp.S = S;
+        dp.logits = logits; dp.scores = scores;
+        TRYK(c, "decode_out", 0, (double)T * 64 * (64 + (logits ? 32 : 0) + (scores ? 32 : 0)), s, launch_decode_out(dp, s));
+    }
+    return 0;
+}
+
+extern "C" int srh_encode_decode(srh_ctx* c, const srh_weights* w, const void* rgb, int rgb_dtype, int B,
+                                 float* mask_logits, float* mask_scores, float* embeddings, void* stream) {
+    if (!c || !w || !rgb || !embeddings || B <= 0) return fail(c, SRH_ERR_BAD_ARG, "srh_encode_decode: bad argument");
+    if (rgb_dtype != SRH_F32 && rgb_dtype != SRH_U8) return fail(c, SRH_ERR_BAD_ARG, "rgb dtype must be f32 or u8");
+    hipSetDevice(c->device);
+    PatchParams pp;
+    pp.src = rgb; pp.src_is_u8 = rgb_dtype == SRH_U8;
+    return encode_batch(c, w, pp, B, mask_logits, mask_scores, embeddings, (hipStream_t)stream);
+}
+
+// ---- TopoNet --------------------------------------------------------------------------------------------
+extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embeddings, const void* points,
+                           int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
+                           int Ns, int K, float* logits, float* scores, void* stream) {
+    if (!c || !w || !embeddings || !points || !pairs || !valid) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet: null argument");
+    if (B <= 0 || N < 0 || Ns < 0) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet: bad sizes");
+    if (K != 16) return fail(c, SRH_ERR_UNSUPPORTED, "n_pairs must be 16 (MAX_NEIGHBOR_QUERIES)");
+    if (points_dtype != SRH_I64 && points_dtype != SRH_F32) return fail(c, SRH_ERR_BAD_ARG, "points dtype must be i64 or f32");
+    if (pairs_dtype != SRH_I64 && pairs_dtype != SRH_I32) return fail(c, SRH_ERR_BAD_ARG, "pairs dtype must be i64 or i32");
+    if (N == 0 || Ns == 0) return 0;
+    hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t NP = (size_t)B * N, R = (size_t)B * Ns * K;
+    int rc = 0;
+    rc |= c->t_feat16.ensure(NP * 256 * 2);
+    rc |= c->t_pf16.ensure(NP * 128 * 2);
+    rc |= c->t_pair16.ensure(R * 320 * 2);
+    rc |= c->t_x.ensure(R * 128 * 4);
+    rc |= c->t_x16.ensure(R * 128 * 2);
+    rc |= c->t_qkv16.ensure(R * 384 * 2);
+    rc |= c->t_at16.ensure(R * 128 * 2);
+    rc |= c->t_y.ensure(R * 128 * 4);
+    rc |= c->t_h16.ensure(R * 128 * 2);
+    if (rc) return fail(c, SRH_ERR_HIP, "toponet workspace allocation failed");
+
+    SampleParams sp;
+    sp.emb = embeddings; sp.points = points; sp.points_i64 = points_dtype == SRH_I64; sp.B = B; sp.N = N;
+    sp.h = w->S; sp.w = w->S; sp.C = 256; sp.patch = (float)w->cfg.patch_size; sp.out_f16 = c->t_feat16.as<f16>();
+    TRYK(c, "bilinear_sample", 0, (double)NP * 256 * 18, s, launch_sample(sp, s));
+    GemmParams g;
+    g.A = c->t_feat16.as<f16>(); g.lda = 256; g.W = w->tp_feat_w; g.ldw = 256; g.M = (int)NP; g.N = 128; g.K = 256;
+    g.bias = w->tp_feat_b; g.act = 2; g.out_f16 = c->t_pf16.as<f16>(); g.ldc16 = 128;
+    TRY(gemm(c, "gemm_toponet", g, s));
+    PairGatherParams pg;
+    pg.pf = c->t_pf16.as<f16>(); pg.points = points; pg.points_i64 = points_dtype == SRH_I64;
+    pg.pairs = pairs; pg.pairs_i64 = pairs_dtype == SRH_I64; pg.B = B; pg.N = N; pg.Ns = Ns; pg.Kp = K;
+    pg.zero_offset = w->cfg.toponet_version == 1; pg.out = c->t_pair16.as<f16>(); pg.ld = 320;
+    TRYK(c, "pair_gather", 0, (double)R * (512 + 640), s, launch_pair_gather(pg, s));
+    GemmParams gp;
+    gp.A = c->t_pair16.as<f16>(); gp.lda = 320; gp.W = w->tp_pair_w; gp.ldw = 320; gp.M = (int)R; gp.N = 128; gp.K = 320;
+    gp.bias = w->tp_pair_b; gp.act = 2; gp.out_f32 = c->t_x.as<float>(); gp.ldc = 128;
+    gp.out_f16 = c->t_x16.as<f16>(); gp.ldc16 = 128;
+    TRY(gemm(c, "gemm_toponet", gp, s));
+    for (const TopoLayerW& tl : w->tlayers) {
+        GemmParams gi;
+        gi.A = c->t_x16.as<f16>(); gi.lda = 128; gi.W = tl.in_w; gi.ldw = 128; gi.M = (int)R; gi.N = 384; gi.K = 128;
+        gi.bias = tl.in_b; gi.out_f16 = c->t_qkv16.as<f16>(); gi.ldc16 = 384;
+        TRY(gemm(c, "gemm_toponet", gi, s));
+        TopoAttnParams ta;
+        ta.qkv = c->t_qkv16.as<f16>(); ta.valid = valid; ta.out = c->t_at16.as<f16>(); ta.nseq = B * Ns;
+        TRYK(c, "topo_attention", 4.0 * R * 16 * 128, 0, s, launch_topo_attention(ta, s));
+        GemmParams go;
+        go.A = c->t_at16.as<f16>(); go.lda = 128; go.W = tl.out_w; go.ldw = 128; go.M = (int)R; go.N = 128; go.K = 128;
+        go.bias = tl.out_b; go.resid = c->t_x.as<float>(); go.ldr = 128; go.out_f32 = c->t_y.as<float>(); go.ldc = 128;
+        TRY(gemm(c, "gemm_toponet", go, s));
+        NormParams ln;
+        ln.x = c->t_y.as<float>(); ln.M = (int)R; ln.D = 128; ln.eps = 1e-5f; ln.gamma = tl.n1_g; ln.beta = tl.n1_b;
+        ln.out_f32 = c->t_x.as<float>(); ln.out_f16 = c->t_x16.as<f16>();
+        TRYK(c, "layernorm", 0, (double)R * 128 * 10, s, launch_layernorm(ln, s));
+        GemmParams g1;
+        g1.A = c->t_x16.as<f16>(); g1.lda = 128; g1.W = tl.l1_w; g1.ldw = 128; g1.M = (int)R; g1.N = 128; g1.K = 128;
+        g1.bias = tl.l1_b; g1.act = 2; g1.out_f16 = c->t_h16.as<f16>(); g1.ldc16 = 128;
+        TRY(gemm(c, "gemm_toponet", g1, s));
+        GemmParams g2;
+        g2.A = c->t_h16.as<f16>(); g2.lda = 128; g2.W = tl.l2_w; g2.ldw = 128; g2.M = (int)R; g2.N = 128; g2.K = 128;
+        g2.bias = tl.l2_b; g2.resid = c->t_x.as<float>(); g2.ldr = 128; g2.out_f32 = c->t_y.as<float>(); g2.ldc = 128;
+        TRY(gemm(c, "gemm_toponet", g2, s));
+        ln.gamma = tl.n2_g; ln.beta = tl.n2_b;
+        TRYK(c, "layernorm", 0, (double)R * 128 * 10, s, launch_layernorm(ln, s));
+    }
+    TopoOutParams to;
+    to.x = c->t_x.as<float>(); to.w = w->tp_out_w; to.rows = (int)R; to.logits = logits; to.scores = scores;
+    TRYK(c, "topo_out", 0, (double)R * 520, s, launch_topo_out(to, w->tp_out_b, s));
+    return 0;
+}
+
+// ---- scene level ------------------------------------------------------------------------------------------
+extern "C" int srh_scene_pass1(srh_ctx* c, const srh_weights* w, const uint8_t* scene, int S, const int32_t* tile_xy,
+                               int n_tiles, int B, float* canvas_kp, float* canvas_road, float* embeddings_all,
+                               void* stream) {
+    if (!c || !w || !scene || !tile_xy || !canvas_kp || !canvas_road || !embeddings_all)
+        return fail(c, SRH_ERR_BAD_ARG, "srh_scene_pass1: null argument");
+    if (n_tiles < 0 || B <= 0 || S < w->cfg.patch_size) return fail(c, SRH_ERR_BAD_ARG, "srh_scene_pass1: bad sizes");
+    hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int P = w->cfg.patch_size;
+    if (c->scores_ws.ensure((size_t)B * P * P * 2 * 4)) return fail(c, SRH_ERR_HIP, "scores workspace allocation failed");
+    const size_t emb_per_tile = (size_t)w->S * w->S * 256;
+    for (int off = 0; off < n_tiles; off += B) {
+        const int nb = std::min(B, n_tiles - off);
+        PatchParams pp;
+        pp.src = scene; pp.src_is_u8 = 1; pp.scene_S = S; pp.tile_xy = tile_xy + 2 * off;
+        TRY(encode_batch(c, w, pp, nb, nullptr, c->scores_ws.as<float>(), embeddings_all + emb_per_tile * off, s));
+        TRYK(c, "scene_add", 0, (double)nb * P * P * 8 * 3, s,
+             launch_scene_add(c->scores_ws.as<float>(), nb, P, tile_xy + 2 * off, canvas_kp, canvas_road, S, s));
+    }
+    return 0;
+}
+
+extern "C" int srh_scene_normalise(srh_ctx* c, const float* canvas_kp, const float* canvas_road, int S,
+                                   const int32_t* tile_xy, int n_tiles, int P, uint8_t* kp_u8, uint8_t* road_u8,
+                                   void* stream) {
+    if (!c || !canvas_kp || !canvas_road || !tile_xy || !kp_u8 || !road_u8)
+        return fail(c, SRH_ERR_BAD_ARG, "srh_scene_normalise: null argument");
+    hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (c->counter.ensure((size_t)S * S * 4)) return fail(c, SRH_ERR_HIP, "counter allocation failed");
+    TRYK(c, "scene_count", 0, (double)S * S * 4, s, launch_scene_count(c->counter.as<float>(), S, tile_xy, n_tiles, P, s));
+    SceneNormParams np;
+    np.canvas_kp = canvas_kp; np.canvas_road = canvas_road; np.counter = c->counter.as<float>();
+    np.kp_u8 = kp_u8; np.road_u8 = road_u8; np.n = S * S;
+    TRYK(c, "scene_normalise", 0, (double)S * S * 14, s, launch_scene_normalise(np, s));
+    return 0;
+}
+
+// ---- op level ------------------------------------------------------------------------------------------------
+extern "C" int srh_op_gemm(srh_ctx* c, const void* A, const void* W, const float* bias, const float* resid, int M,
+                           int N, int K, int act, float* out_f32, void* out_f16, void* stream) {
+    if (!c || !A || !W) return fail(c, SRH_ERR_BAD_ARG, "srh_op_gemm: null argument");
+    hipSetDevice(c->device);
+    GemmParams g;
+    g.A = (const f16*)A; g.lda = K; g.W = (const f16*)W; g.ldw = K; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.resid = resid; g.ldr = N; g.act = act;
+    g.out_f32 = out_f32; g.ldc = N; g.out_f16 = (f16*)out_f16; g.ldc16 = N;
+    return gemm(c, "gemm_op", g, (hipStream_t)stream);
+}
+
+extern "C" int srh_op_conv3x3(srh_ctx* c, const void* A, const void* W, int B, int S, int C, int N, float* out_f32,
+                              void* stream) {
+    if (!c || !A || !W || !out_f32) return fail(c, SRH_ERR_BAD_ARG, "srh_op_conv3x3: null argument");
+    hipSetDevice(c->device);
+    GemmParams g;
+    g.A = (const f16*)A; g.lda = C; g.W = (const f16*)W; g.ldw = 9 * C; g.M = B * S * S; g.N = N; g.K = 9 * C;
+    g.conv_S = S; g.conv_C = C; g.out_f32 = out_f32; g.ldc = N;
+    return gemm(c, "gemm_op", g, (hipStream_t)stream);
+}
+
+extern "C" int srh_op_layernorm(srh_ctx* c, const float* x, const float* gamma, const float* beta, float eps, int M,
+                                int D, int gelu, float* out_f32, void* out_f16, void* stream) {
+    if (!c || !x) return fail(c, SRH_ERR_BAD_ARG, "srh_op_layernorm: null argument");
+    hipSetDevice(c->device);
+    NormParams ln;
+    ln.x = x; ln.M = M; ln.D = D; ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.act = gelu;
+    ln.out_f32 = out_f32; ln.out_f16 = (f16*)out_f16;
+    hipStream_t s = (hipStream_t)stream;
+    TRYK(c, "layernorm", 0, 0, s, launch_layernorm(ln, s));
+    return 0;
+}
+
+extern "C" int srh_op_attention(srh_ctx* c, const void* qkv, const void* rel_h, const void* rel_w, const void* bias_qkv,
+                                int B, int S, int heads, int win, void* out, void* stream) {
+    if (!c || !qkv || !rel_h || !rel_w || !bias_qkv || !out) return fail(c, SRH_ERR_BAD_ARG, "srh_op_attention: null argument");
+    hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int hd = 64, D = heads * hd;
+    const size_t T = (size_t)B * S * S;
+    if (c->rel.ensure(T * heads * 64 * 4)) return fail(c, SRH_ERR_HIP, "rel workspace allocation failed");
+    RelPosParams rp;
+    rp.qkv = (const f16*)qkv; rp.ld = 3 * D; rp.table_h = (const f16*)rel_h; rp.table_w = (const f16*)rel_w;
+    rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = win; rp.inv_scale = 8.f;
+    TRYK(c, "relpos", 0, 0, s, launch_relpos(rp, s));
+    AttnParams ap;
+    ap.qkv = (const f16*)qkv; ap.ld = 3 * D; ap.rel = c->rel.as<float>(); ap.bias_qkv = (const f16*)bias_qkv;
+    ap.out = (f16*)out; ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = win; ap.scale = 0.125f;
+    TRYK(c, "attention", attn_flops(B, S, heads, hd, win), 0, s, launch_attention(ap, s));
+    return 0;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------------
+extern "C" int srh_profile_enable(srh_ctx* c, int on) {
+    if (!c) return SRH_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    c->profiling = on != 0;
+    c->prof.clear();
+    c->ev_used = 0;
+    return 0;
+}
+
+extern "C" int srh_profile_read(srh_ctx* c, srh_profile_row* rows, int max_rows, int* n_rows) {
+    if (!c || !rows || !n_rows) return SRH_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(c, e, "hipDeviceSynchronize");
+    std::vector<srh_profile_row> acc(c->cls_names.size());
+    for (size_t i = 0; i < acc.size(); ++i) {
+        memset(&acc[i], 0, sizeof(srh_profile_row));
+        snprintf(acc[i].name, sizeof(acc[i].name), "%s", c->cls_names[i].c_str());
+    }
+    for (const ProfEntry& pe : c->prof) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pe.e0, pe.e1);
+        acc[pe.cls].launches += 1;
+        acc[pe.cls].ms += ms;
+        acc[pe.cls].flops += pe.flops;
+        acc[pe.cls].bytes += pe.bytes;
+    }
+    int k = 0;
+    for (size_t i = 0; i < acc.size() && k < max_rows; ++i)
+        if (acc[i].launches) rows[k++] = acc[i];
+    *n_rows = k;
+    c->prof.clear();
+    c->ev_used = 0;
+    return 0;
+}

@@ -1,0 +1,359 @@
+// SAM ViT attention with decomposed rel-pos bias: 14x14 windowed (8 of 12 ViT-B blocks) and global
+// (blocks 2/5/8/11).  Replaces K5/K6 of SURVEY.md §2.1 (fork image_encoder.py Attention.forward +
+// window_partition / window_unpartition), semantics per SURVEY App. B.3/B.4:
+//   * softmax(scale * q.k^T + rel_h[q,kh] + rel_w[q,kw]) v, rel terms from the unscaled q;
+//   * window padding happens AFTER LayerNorm, so pad tokens are REAL keys with k = b_k, v = b_v
+//     (they receive softmax mass); pad QUERIES are never evaluated (their rows are cropped).
+//
+// gfx950 design.  Everything is issued transposed so that one lane owns one query:
+//   S^T[key, q] = K[key,:] . Q[q,:]      A operand = K rows (LDS), B operand = Q rows (registers)
+//   O^T[d,   q] = V^T[d,key] . P^T[key,q] A operand = V^T rows (LDS), B operand = P (registers)
+// with v_mfma_f32_32x32x16_f16.  In the C/D layout lane l holds query (l & 31) and 16 of the 32 keys
+// (rows (r&3) + 8(r>>2) + 4(l>>5)), so the softmax max/sum are lane-local plus ONE cross-half
+// exchange, the running rescale is lane-local, and the exponentiated tile is ALREADY the B fragment
+// of the P.V product if V^T is stored with the same key permutation — no P round trip through LDS.
+// The rel-pos bias enters as the MFMA accumulator's initial value (f32, pre-divided by scale).
+// Key tiles hold 32 MFMA rows = whole window rows (2 rows of 14 -> 28 valid keys, 2 rows of 16, or
+// 1 row of 32), so the per-lane rel_w values repeat for every tile and rel_h is 1-2 scalars per tile.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace srh {
+
+constexpr int HD = 64;  // head dim of ViT-B / ViT-L (ViT-H's 80 is not built yet)
+
+template <int WIN> struct Geom;
+template <> struct Geom<14> { static constexpr int KPT = 28, RPT = 2, NT = 7, WP = 16; };
+template <> struct Geom<16> { static constexpr int KPT = 32, RPT = 2, NT = 8, WP = 16; };
+template <> struct Geom<32> { static constexpr int KPT = 32, RPT = 1, NT = 32, WP = 32; };
+
+// local MFMA row i of a key tile -> (row-in-tile, col) of the window
+template <int WIN> __device__ __forceinline__ void tile_rc(int i, int& r, int& c) {
+    if (WIN == 32) { r = 0; c = i; }
+    else if (WIN == 16) { r = i >> 4; c = i & 15; }
+    else { r = i >= 14; c = i - 14 * r; }
+}
+
+// V^T slot of local key i: the key permutation that makes exp(S^T) registers the P^T B-fragment
+__device__ __forceinline__ int vt_slot(int i) {
+    const int half = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
+    return ((reg >> 3) * 2 + half) * 8 + (reg & 7);
+}
+
+struct QState {
+    f16x8 q[4];        // B fragments of the lane's query, 4 k-steps of 16
+    float relw[16];    // rel_w / scale at the lane's 16 keys of a tile (tile-invariant)
+    float m, l;        // running max (raw units) and this half's partial row sum
+    f32x16 o[2];       // O^T accumulators, d tiles 0..31 / 32..63
+};
+
+template <int WIN>
+__device__ __forceinline__ void attn_tile(QState& st, const char* k_lds, const char* vt_lds,
+                                          float rh0, float rh1, float c_exp, int lane) {
+    const int half = lane >> 5, row = lane & 31;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float rh = rh0;
+        if (WIN == 16) rh = r >= 8 ? rh1 : rh0;
+        if (WIN == 14) rh = (r >= 8 || (half == 1 && r >= 6)) ? rh1 : rh0;
+        s[r] = st.relw[r] + rh;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 a = *reinterpret_cast<const f16x8*>(k_lds + row * 128 + swz8(row, ks * 2 + half) * 16);
+        s = mfma32(a, st.q[ks], s);
+    }
+    if (WIN == 14) {
+#pragma unroll
+        for (int r = 12; r < 16; ++r) s[r] = half ? -INFINITY : s[r];   // rows 28..31 are not keys
+    }
+    float mloc = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(st.m, mloc);
+    const float alpha = exp2f((st.m - m_new) * c_exp);
+    st.m = m_new;
+    float sum = 0.f;
+    f16x8 pb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f((s[r] - m_new) * c_exp);
+        sum += pv;
+        pb[r >> 3][r & 7] = (f16)pv;
+    }
+    st.l = st.l * alpha + sum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const int d = dt * 32 + row;
+            const int c = (sx * 2 + half) ^ ((d >> 2) & 3);
+            const f16x8 a = *reinterpret_cast<const f16x8*>(vt_lds + d * 64 + c * 16);
+            st.o[dt] = mfma32(a, pb[sx], st.o[dt]);
+        }
+    }
+}
+
+template <int WIN>
+__device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size_t tok, int head, int lane) {
+    const int half = lane >> 5;
+    const f16* q = p.qkv + tok * p.ld + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st.q[ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
+    const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP) + Geom<WIN>::WP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int rr, cc;
+        tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
+        st.relw[r] = (cc < WIN) ? rel[cc] : 0.f;
+    }
+    st.m = -INFINITY;
+    st.l = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
+}
+
+__device__ __forceinline__ void store_query(const QState& st, const AttnParams& p, size_t tok, int head,
+                                            int lane, bool valid) {
+    const int half = lane >> 5;
+    const float inv = 1.0f / (st.l + __shfl_xor(st.l, 32, 64));
+    if (!valid) return;
+    f16* o = p.out + tok * p.ldo + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            f16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (f16)(st.o[dt][qd * 4 + e] * inv);
+            *reinterpret_cast<f16x4*>(o + dt * 32 + 8 * qd + 4 * half) = h;
+        }
+}
+
+// Stage a 4-key x 8-dim block of V into the transposed, key-permuted V^T tile.
+__device__ __forceinline__ uint32_t u4_word(const uint4& v, int i) {
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ uint32_t u4_half(const uint4& v, int e) {   // e-th fp16 of the 8
+    const uint32_t w = u4_word(v, e >> 1);
+    return (e & 1) ? (w >> 16) : (w & 0xffffu);
+}
+__device__ __forceinline__ void vt_write(char* vt, int kq, int dc, const uint4& v0, const uint4& v1,
+                                         const uint4& v2, const uint4& v3) {
+    const int slot = vt_slot(kq * 4);
+    const int c = slot >> 3, eo = slot & 7;   // eo is 0 or 4
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int d = dc * 8 + e;
+        uint2 w;
+        w.x = u4_half(v0, e) | (u4_half(v1, e) << 16);
+        w.y = u4_half(v2, e) | (u4_half(v3, e) << 16);
+        *reinterpret_cast<uint2*>(vt + d * 64 + ((c ^ ((d >> 2) & 3)) * 16) + eo * 2) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Windowed attention: one workgroup per (image, head, window); the whole window's K and V^T
+// (196 keys incl. pad keys) are staged once, then each wave walks its 32-query tiles.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIN_LDS_K = 7 * 4096, WIN_LDS_VT = 7 * 4096, WIN_LDS_RH = 4 * 32 * 17 * 4;
+constexpr int WIN_LDS = WIN_LDS_K + WIN_LDS_VT + WIN_LDS_RH;
+
+__global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
+    constexpr int WIN = 14;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* vt_lds = smem + WIN_LDS_K;
+    float* rh_lds = reinterpret_cast<float*>(smem + WIN_LDS_K + WIN_LDS_VT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S, nw = (S + WIN - 1) / WIN, D = p.heads * HD;
+    int u = blockIdx.x;
+    const int head = u % p.heads; u /= p.heads;
+    const int widx = u % (nw * nw); u /= (nw * nw);
+    const int b = u;
+    const int wy = widx / nw, wx = widx % nw;
+    const int nry = min(WIN, S - wy * WIN), nrx = min(WIN, S - wx * WIN);
+    const int nreal = nry * nrx;
+
+    // ---- stage K rows: items (tile, local row i, 16-byte chunk c)
+    for (int it = tid; it < 7 * 32 * 8; it += 256) {
+        const int c = it & 7, i = (it >> 3) & 31, t = it >> 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < 28) {
+            int rr, cc;
+            tile_rc<WIN>(i, rr, cc);
+            const int y = wy * WIN + t * 2 + rr, x = wx * WIN + cc;
+            const f16* src = (y < S && x < S)
+                ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + D + head * HD
+                : p.bias_qkv + D + head * HD;
+            v = *reinterpret_cast<const uint4*>(src + c * 8);
+        }
+        *reinterpret_cast<uint4*>(k_lds + t * 4096 + i * 128 + swz8(i, c) * 16) = v;
+    }
+    // ---- stage V^T: items (tile, key quad, d chunk)
+    for (int it = tid; it < 7 * 8 * 8; it += 256) {
+        const int dc = it & 7, kq = (it >> 3) & 7, t = it >> 6;
+        uint4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = kq * 4 + e;
+            v[e] = make_uint4(0, 0, 0, 0);
+            if (i < 28) {
+                int rr, cc;
+                tile_rc<WIN>(i, rr, cc);
+                const int y = wy * WIN + t * 2 + rr, x = wx * WIN + cc;
+                const f16* src = (y < S && x < S)
+                    ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + 2 * D + head * HD
+                    : p.bias_qkv + 2 * D + head * HD;
+                v[e] = *reinterpret_cast<const uint4*>(src + dc * 8);
+            }
+        }
+        vt_write(vt_lds + t * 4096, kq, dc, v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+
+    const float c_exp = p.scale * 1.4426950408889634f;
+    float* rh = rh_lds + wave * 32 * 17;
+    const int ntq = (nreal + 31) / 32;
+    for (int jt = wave; jt < ntq; jt += 4) {
+        const int qi_raw = jt * 32 + (lane & 31);
+        const bool valid = qi_raw < nreal;
+        const int qi = valid ? qi_raw : nreal - 1;
+        const int ry = qi / nrx, rx = qi % nrx;
+        const size_t tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
+        QState st;
+        load_query<WIN>(st, p, tok, head, lane);
+        // this wave's rel_h table: rh[q][kh], lanes split the 14 values between the two halves
+        {
+            const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP);
+            const int half = lane >> 5;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rh[(lane & 31) * 17 + half * 8 + e] = rel[half * 8 + e];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int t = 0; t < 7; ++t) {
+            const float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
+            attn_tile<WIN>(st, k_lds + t * 4096, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
+        }
+        store_query(st, p, tok, head, lane, valid);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global attention: one workgroup per (image, head, 128-query block); K / V^T streamed through a
+// double-buffered LDS ring, 2 key tiles (64 MFMA rows) per stage, next stage's global loads issued
+// before the current stage's MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int WIN>
+__global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
+    constexpr int NT = Geom<WIN>::NT, WP = Geom<WIN>::WP, RPT = Geom<WIN>::RPT;
+    constexpr int STAGE = 2 * 4096 + 2 * 4096;   // 2 K tiles + 2 V^T tiles
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * 32 * (WP + 1) * 4];
+    float* rh_lds = reinterpret_cast<float*>(smem + 2 * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S, D = p.heads * HD;
+    const int nqb = (S * S) / 128;
+    int u = blockIdx.x;
+    const int qb = u % nqb; u /= nqb;
+    const int head = u % p.heads; u /= p.heads;
+    const int b = u;
+    const size_t tok0 = (size_t)b * S * S;
+
+    const int qi = qb * 128 + wave * 32 + (lane & 31);
+    const size_t tok = tok0 + qi;
+    QState st;
+    load_query<WIN>(st, p, tok, head, lane);
+    float* rh = rh_lds + wave * 32 * (WP + 1);
+    {
+        const float* rel = p.rel + (tok * p.heads + head) * (2 * WP);
+        const int half = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < WP / 2; ++e) rh[(lane & 31) * (WP + 1) + half * (WP / 2) + e] = rel[half * (WP / 2) + e];
+    }
+
+    // staging registers: 2 K chunks per thread, one V^T block for threads < 128
+    uint4 rk[2], rv[4];
+    auto load_stage = [&](int sidx) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int it = tid + 256 * e;            // (tile-in-stage, row i, chunk c)
+            const int c = it & 7, i = (it >> 3) & 31, t = sidx * 2 + (it >> 8);
+            const size_t ktok = tok0 + (size_t)t * 32 + i;
+            rk[e] = *reinterpret_cast<const uint4*>(p.qkv + ktok * p.ld + D + head * HD + c * 8);
+        }
+        if (tid < 128) {
+            const int dc = tid & 7, kq = (tid >> 3) & 7, t = sidx * 2 + (tid >> 6);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t ktok = tok0 + (size_t)t * 32 + kq * 4 + e;
+                rv[e] = *reinterpret_cast<const uint4*>(p.qkv + ktok * p.ld + 2 * D + head * HD + dc * 8);
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int it = tid + 256 * e;
+            const int c = it & 7, i = (it >> 3) & 31, tl = it >> 8;
+            *reinterpret_cast<uint4*>(base + tl * 4096 + i * 128 + swz8(i, c) * 16) = rk[e];
+        }
+        if (tid < 128) {
+            const int dc = tid & 7, kq = (tid >> 3) & 7, tl = tid >> 6;
+            vt_write(base + 8192 + tl * 4096, kq, dc, rv[0], rv[1], rv[2], rv[3]);
+        }
+    };
+
+    const float c_exp = p.scale * 1.4426950408889634f;
+    constexpr int NSTAGE = NT / 2;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int sidx = 0; sidx < NSTAGE; ++sidx) {
+        const int buf = sidx & 1;
+        if (sidx + 1 < NSTAGE) load_stage(sidx + 1);
+        const char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int t = sidx * 2 + tl;
+            const float rh0 = rh[(lane & 31) * (WP + 1) + t * RPT];
+            const float rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + t * RPT + 1] : 0.f;
+            attn_tile<WIN>(st, base + tl * 4096, base + 8192 + tl * 4096, rh0, rh1, c_exp, lane);
+        }
+        if (sidx + 1 < NSTAGE) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    store_query(st, p, tok, head, lane, true);
+}
+
+int launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.hd != HD) return -2;
+    if (p.win == p.S) {
+        const int grid = p.B * p.heads * (p.S * p.S / 128);
+        if (p.S == 32) hipLaunchKernelGGL(attn_global_kernel<32>, dim3(grid), dim3(256), 0, s, p);
+        else if (p.S == 16) hipLaunchKernelGGL(attn_global_kernel<16>, dim3(grid), dim3(256), 0, s, p);
+        else return -2;
+    } else if (p.win == 14) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+            attr_set = true;
+        }
+        const int nw = (p.S + 13) / 14;
+        hipLaunchKernelGGL(attn_window_kernel, dim3(p.B * nw * nw * p.heads), dim3(256), WIN_LDS, s, p);
+    } else {
+        return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace srh

@@ -1,0 +1,128 @@
+// Tail of the naive map decoder and the scene-level mask fusion.
+//
+// Reference: model.py:286-295 (ConvTranspose2d k2 s2 x4, LayerNorm2d, exact GELU), :445-446/:490-494
+// (sigmoid, NCHW -> NHWC) and inferencer.py:79-110 (scatter-add of the two masks + coverage
+// counter, divide, x255, truncate to u8).
+//
+// A stride-2 kernel-2 transposed conv does not overlap: every input pixel owns a 2x2 output
+// block, so each layer is a per-pixel GEMM to 4*Cout columns (done by gemm.hip) and the rows of
+// the successive activations are in quad-tree order (pixel, sub1, sub2, sub3).  This file holds the
+// last layer (32 -> 2 channels, N = 8: too thin for MFMA), fused with the sigmoid and with the
+// quad-tree -> row-major NHWC scatter; it is write-bound (16 B/px logits+scores).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace srh {
+
+__global__ __launch_bounds__(256) void decode_out_kernel(DecodeOutParams p) {
+    const long rows = (long)p.B * p.S * p.S * 64;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float x[32];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.x + row * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 t = src[i];
+            const f16* h = reinterpret_cast<const f16*>(&t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[i * 8 + e] = (float)h[e];
+        }
+    }
+    float o[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        float a = p.bias[n & 1];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) a = fmaf(x[c], p.w[n * 32 + c], a);
+        o[n] = a;
+    }
+    long r = row;
+    const int s3 = r & 3; r >>= 2;
+    const int s2 = r & 3; r >>= 2;
+    const int s1 = r & 3; r >>= 2;
+    const int px = r % p.S; r /= p.S;
+    const int py = r % p.S; r /= p.S;
+    const int b = (int)r;
+    const int P = p.S * 16;
+    const int y = (((py * 2 + (s1 >> 1)) * 2 + (s2 >> 1)) * 2 + (s3 >> 1)) * 2;
+    const int xx = (((px * 2 + (s1 & 1)) * 2 + (s2 & 1)) * 2 + (s3 & 1)) * 2;
+#pragma unroll
+    for (int ky = 0; ky < 2; ++ky) {
+        const size_t off = (((size_t)b * P + y + ky) * P + xx) * 2;
+        const float4 lg = make_float4(o[ky * 4 + 0], o[ky * 4 + 1], o[ky * 4 + 2], o[ky * 4 + 3]);
+        if (p.logits) *reinterpret_cast<float4*>(p.logits + off) = lg;
+        if (p.scores) {
+            const float4 sc = make_float4(1.f / (1.f + expf(-lg.x)), 1.f / (1.f + expf(-lg.y)),
+                                          1.f / (1.f + expf(-lg.z)), 1.f / (1.f + expf(-lg.w)));
+            *reinterpret_cast<float4*>(p.scores + off) = sc;
+        }
+    }
+}
+
+int launch_decode_out(const DecodeOutParams& p, hipStream_t s) {
+    const long rows = (long)p.B * p.S * p.S * 64;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(decode_out_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- scene fusion -----------------------------------------------------------------------------
+// One thread per canvas pixel walks the batch's tiles IN ORDER, so the f32 summation order is the
+// reference's sequential `canvas[y0:y1, x0:x1] += patch` order (deterministic; no atomics).
+__global__ __launch_bounds__(256) void scene_add_kernel(const float* scores, int B, int P, const int* tile_xy,
+                                                        float* kp, float* road, int S) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)S * S) return;
+    const int x = gid % S, y = gid / S;
+    float a = kp[gid], r = road[gid];
+    bool touched = false;
+    for (int t = 0; t < B; ++t) {
+        const int x0 = tile_xy[2 * t], y0 = tile_xy[2 * t + 1];
+        const int lx = x - x0, ly = y - y0;
+        if (lx >= 0 && lx < P && ly >= 0 && ly < P) {
+            const float2 v = *reinterpret_cast<const float2*>(scores + (((size_t)t * P + ly) * P + lx) * 2);
+            a += v.x; r += v.y; touched = true;
+        }
+    }
+    if (touched) { kp[gid] = a; road[gid] = r; }
+}
+
+__global__ __launch_bounds__(256) void scene_count_kernel(float* counter, int S, const int* tile_xy, int n, int P) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)S * S) return;
+    const int x = gid % S, y = gid / S;
+    float c = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const int lx = x - tile_xy[2 * t], ly = y - tile_xy[2 * t + 1];
+        if (lx >= 0 && lx < P && ly >= 0 && ly < P) c += 1.f;
+    }
+    counter[gid] = c;
+}
+
+__global__ __launch_bounds__(256) void scene_norm_kernel(SceneNormParams p) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= p.n) return;
+    const float c = p.counter[gid];
+    // (canvas / counter) * 255 -> uint8 truncation; 0/0 = NaN casts to 0 in the reference (App. D.2)
+    const float a = (p.canvas_kp[gid] / c) * 255.f, r = (p.canvas_road[gid] / c) * 255.f;
+    p.kp_u8[gid] = (c > 0.f) ? (uint8_t)a : (uint8_t)0;
+    p.road_u8[gid] = (c > 0.f) ? (uint8_t)r : (uint8_t)0;
+}
+
+int launch_scene_add(const float* scores, int B, int P, const int* tile_xy, float* kp, float* road, int S, hipStream_t s) {
+    const long n = (long)S * S;
+    hipLaunchKernelGGL(scene_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, B, P, tile_xy, kp, road, S);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_scene_count(float* counter, int S, const int* tile_xy, int n_tiles, int P, hipStream_t s) {
+    const long n = (long)S * S;
+    hipLaunchKernelGGL(scene_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, counter, S, tile_xy, n_tiles, P);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_scene_normalise(const SceneNormParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(scene_norm_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace srh

@@ -1,0 +1,121 @@
+// Host-side launch interface of the HIP kernels (internal; the public surface is include/samroad_hip.h).
+#pragma once
+#include "common.hpp"
+
+namespace srh {
+
+struct GemmParams {
+    const f16* A = nullptr; int lda = 0;       // activations [M,K] row-major fp16
+    const f16* W = nullptr; int ldw = 0;       // weights     [N,K] row-major fp16
+    int M = 0, N = 0, K = 0;
+    const float* bias = nullptr;               // [N]
+    const float* resid = nullptr; int ldr = 0; // f32 [M,N], may alias out_f32 (in-place residual)
+    const float* pos = nullptr; int pos_rows = 1;  // f32 [pos_rows,N], row m % pos_rows
+    float* out_f32 = nullptr; int ldc = 0;
+    f16* out_f16 = nullptr; int ldc16 = 0;
+    int act = 0;                               // 0 none, 1 exact-erf GELU, 2 ReLU (applied after bias)
+    int conv_S = 0, conv_C = 0;                // >0: implicit 3x3 conv over [B,S,S,C]
+};
+int launch_gemm(const GemmParams& p, hipStream_t s);
+
+// Row LayerNorm (biased variance) f32 [M,D] -> fp16 and/or f32; gamma == nullptr => cast only.
+struct NormParams {
+    const float* x = nullptr; int M = 0, D = 0;
+    const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-6f;
+    int act = 0;                               // 1: GELU after affine
+    f16* out_f16 = nullptr; float* out_f32 = nullptr;
+};
+int launch_layernorm(const NormParams& p, hipStream_t s);
+
+// Tile batcher + pixel normalise + patch im2col (K1/K2 prologue).
+struct PatchParams {
+    const void* src = nullptr;   // f32 [B,P,P,3] tiles (scene_S == 0) or u8/f32 scene [S,S,3]
+    int src_is_u8 = 0;
+    int B = 0, P = 0;
+    int scene_S = 0;             // >0: crop tiles out of a resident scene at tile_xy
+    const int* tile_xy = nullptr;  // device [B,2] (x0,y0)
+    f16* out = nullptr;          // [B*(P/16)^2, 768] with k = ky*48 + kx*3 + c
+};
+int launch_patch_im2col(const PatchParams& p, hipStream_t s);
+
+// Decomposed rel-pos bias (K5/K6 bias term): rel[token, head, 0:Wp] = inv_scale * q . Rh[qh, kh],
+// rel[token, head, Wp:2Wp] = inv_scale * q . Rw[qw, kw]   (f32; Wp = win rounded up to 16)
+struct RelPosParams {
+    const f16* qkv = nullptr; int ld = 0;   // [tokens, 3*D]
+    const f16* table_h = nullptr;           // [2*win-1, hd] fp16
+    const f16* table_w = nullptr;
+    float* rel = nullptr;                   // [tokens, heads, 2*Wp]
+    int B = 0, S = 0, heads = 0, hd = 0, win = 0;
+    float inv_scale = 8.f;
+};
+int launch_relpos(const RelPosParams& p, hipStream_t s);
+
+// Windowed / global attention with rel-pos bias; pad tokens are real keys with k = b_k, v = b_v.
+struct AttnParams {
+    const f16* qkv = nullptr; int ld = 0;   // [tokens, 3*D]: q | k | v, each head-major
+    const float* rel = nullptr;             // from launch_relpos
+    const f16* bias_qkv = nullptr;          // [3*D] fp16 (pad-token k / v rows)
+    f16* out = nullptr; int ldo = 0;        // [tokens, D]
+    int B = 0, S = 0, heads = 0, hd = 0, win = 0;  // win == S => global
+    float scale = 0.125f;
+};
+int launch_attention(const AttnParams& p, hipStream_t s);
+
+// map_decoder last stage: ConvT(32->2,k2s2) + sigmoid + quad-tree -> NHWC scatter.
+struct DecodeOutParams {
+    const f16* x = nullptr;      // [B*S*S*64, 32] rows in quad-tree order (px, sub1, sub2, sub3)
+    const float* w = nullptr;    // [8,32]: n = (ky*2+kx)*2 + class
+    const float* bias = nullptr; // [2]
+    int B = 0, S = 0;            // S = tokens per side (P/16)
+    float* logits = nullptr;     // nullable [B,P,P,2]
+    float* scores = nullptr;     // nullable [B,P,P,2]
+    // optional fused scene scatter-add: canvas[(y0+y)*scene_S + x0+x] += score
+    float* canvas_kp = nullptr; float* canvas_road = nullptr; int scene_S = 0; const int* tile_xy = nullptr;
+};
+int launch_decode_out(const DecodeOutParams& p, hipStream_t s);
+
+// Scene canvases -> u8 masks (divide by analytic coverage count, x255, truncate; uncovered -> 0).
+struct SceneNormParams {
+    const float* canvas_kp = nullptr; const float* canvas_road = nullptr;
+    const float* counter = nullptr;  // f32 [S,S] coverage count
+    uint8_t* kp_u8 = nullptr; uint8_t* road_u8 = nullptr; int n = 0;
+};
+int launch_scene_normalise(const SceneNormParams& p, hipStream_t s);
+int launch_scene_count(float* counter, int scene_S, const int* tile_xy, int n_tiles, int P, hipStream_t s);
+int launch_scene_add(const float* scores, int B, int P, const int* tile_xy, float* kp, float* road, int scene_S, hipStream_t s);
+
+// Bilinear sampler (F.grid_sample, align_corners=False, zeros) on channels-last embeddings.
+struct SampleParams {
+    const float* emb = nullptr;    // [B,h,w,C] channels-last f32
+    const void* points = nullptr; int points_i64 = 0;  // [B,N,2] (x,y) pixels, int64 or f32
+    int B = 0, N = 0, h = 0, w = 0, C = 0; float patch = 512.f;
+    f16* out_f16 = nullptr; float* out_f32 = nullptr;   // [B*N, C]
+};
+int launch_sample(const SampleParams& p, hipStream_t s);
+
+// TopoNet helpers.
+struct PairGatherParams {
+    const f16* pf = nullptr;        // relu(feature_proj) [B*N,128] fp16
+    const void* points = nullptr; int points_i64 = 0;
+    const void* pairs = nullptr; int pairs_i64 = 0;   // [B,Ns,K,2]
+    int B = 0, N = 0, Ns = 0, Kp = 0; int zero_offset = 0;
+    f16* out = nullptr; int ld = 0;  // [B*Ns*K, ld>=258] = src | tgt | dx dy | 0...
+};
+int launch_pair_gather(const PairGatherParams& p, hipStream_t s);
+
+struct TopoAttnParams {
+    const f16* qkv = nullptr;       // [nseq*16, 384]
+    const uint8_t* valid = nullptr; // [nseq,16]
+    f16* out = nullptr;             // [nseq*16, 128]
+    int nseq = 0;
+};
+int launch_topo_attention(const TopoAttnParams& p, hipStream_t s);
+
+struct TopoOutParams {
+    const float* x = nullptr;       // [rows,128] f32
+    const float* w = nullptr; float b = 0.f;
+    int rows = 0; float* logits = nullptr; float* scores = nullptr;
+};
+int launch_topo_out(const TopoOutParams& p, const float* bias_dev, hipStream_t s);
+
+}  // namespace srh

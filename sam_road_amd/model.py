@@ -1,0 +1,302 @@
+"""`SAMRoad` — drop-in inference surface of the reference's LightningModule (reference
+model.py:190-508) backed by the gfx950 HIP library (C ABI in include/samroad_hip.h).
+
+Same constructor (`SAMRoad(config)`), same `state_dict` key names and shapes, same
+three entry points with the same argument meaning:
+
+    infer_masks_and_img_features(rgb)                       model.py:459-495
+    infer_toponet(image_embeddings, graph_points, pairs, valid)   model.py:498-508
+    forward(rgb, graph_points, pairs, valid)                model.py:414-457
+
+The module tree below only HOLDS parameters (so `load_state_dict(strict=True)`, `.eval()`,
+`.to(device)` behave as in the reference); no arithmetic runs in PyTorch.  There is no CPU path: a
+call without the built library or without an MI355X raises.  Training (`training_step`, losses,
+optimizers: model.py:349-363,511-685) is out of scope.
+"""
+import ctypes as C
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from . import _lib
+
+ARCH = {  # model.py:197-218
+    "vit_b": dict(embed_dim=768, depth=12, num_heads=12, global_attn_indexes=[2, 5, 8, 11]),
+    "vit_l": dict(embed_dim=1024, depth=24, num_heads=16, global_attn_indexes=[5, 11, 17, 23]),
+    "vit_h": dict(embed_dim=1280, depth=32, num_heads=16, global_attn_indexes=[7, 15, 23, 31]),
+}
+
+
+class _LayerNorm2dParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _LoRAQkvParams(nn.Module):
+    """Key layout of the reference's `_LoRA_qkv` (model.py:152-186): weight/bias keep their names and
+    four rank-r adapters are added.  Folded into qkv.weight at pack time."""
+
+    def __init__(self, dim, r):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(3 * dim, dim))
+        self.bias = nn.Parameter(torch.zeros(3 * dim))
+        self.linear_a_q = nn.Linear(dim, r, bias=False)
+        self.linear_b_q = nn.Linear(r, dim, bias=False)
+        self.linear_a_v = nn.Linear(dim, r, bias=False)
+        self.linear_b_v = nn.Linear(r, dim, bias=False)
+        nn.init.zeros_(self.linear_b_q.weight)
+        nn.init.zeros_(self.linear_b_v.weight)
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, dim, heads, grid, lora_rank):
+        super().__init__()
+        self.qkv = _LoRAQkvParams(dim, lora_rank) if lora_rank else nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+        self.rel_pos_h = nn.Parameter(torch.zeros(2 * grid - 1, dim // heads))
+        self.rel_pos_w = nn.Parameter(torch.zeros(2 * grid - 1, dim // heads))
+
+
+class _MlpParams(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.lin1 = nn.Linear(dim, 4 * dim)
+        self.lin2 = nn.Linear(4 * dim, dim)
+
+
+class _BlockParams(nn.Module):
+    def __init__(self, dim, heads, grid, lora_rank):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _AttnParams(dim, heads, grid, lora_rank)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _MlpParams(dim)
+
+
+class _PatchEmbedParams(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=16, stride=16)
+
+
+class _ImageEncoderParams(nn.Module):
+    """Parameter layout of the fork's ImageEncoderViT as constructed at model.py:245-258."""
+
+    def __init__(self, img_size, embed_dim, depth, num_heads, global_attn_indexes, lora_rank=0):
+        super().__init__()
+        self.img_size = img_size  # read at model.py:439
+        grid = img_size // 16
+        self.patch_embed = _PatchEmbedParams(embed_dim)
+        self.pos_embed = nn.Parameter(torch.zeros(1, grid, grid, embed_dim))
+        self.blocks = nn.ModuleList([
+            _BlockParams(embed_dim, num_heads, grid if i in global_attn_indexes else 14, lora_rank)
+            for i in range(depth)])
+        self.neck = nn.Sequential(nn.Conv2d(embed_dim, 256, 1, bias=False), _LayerNorm2dParams(256),
+                                  nn.Conv2d(256, 256, 3, padding=1, bias=False), _LayerNorm2dParams(256))
+
+
+class _TopoNetParams(nn.Module):
+    def __init__(self, version):
+        super().__init__()
+        self.feature_proj = nn.Linear(256, 128)
+        self.pair_proj = nn.Linear(258, 128)
+        if version != "no_transformer":
+            layer = nn.TransformerEncoderLayer(d_model=128, nhead=4, dim_feedforward=128, dropout=0.1,
+                                               activation="relu", batch_first=True)
+            self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=3)
+        self.output_proj = nn.Linear(128, 1)
+
+
+class SAMRoad(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        assert config.SAM_VERSION in {"vit_b", "vit_l", "vit_h"}  # model.py:197
+        if config.NO_SAM:
+            raise NotImplementedError("NO_SAM ablation is not part of the release (reference model.py:232-242)")
+        if config.USE_SAM_DECODER:
+            raise NotImplementedError("USE_SAM_DECODER (SAM MaskDecoder branch, archived configs only) is not "
+                                      "built yet: SURVEY.md §8(f) rank 4")
+        arch = dict(ARCH[config.SAM_VERSION])
+        if config.ENCODER_DEPTH:  # test hook, not a reference key (absent => falsy => ignored)
+            arch["depth"] = int(config.ENCODER_DEPTH)
+            arch["global_attn_indexes"] = [int(i) for i in (config.ENCODER_GLOBAL_ATTN_INDEXES or [])]
+        self.arch = arch
+        self.image_size = config.PATCH_SIZE
+        self.register_buffer("pixel_mean", torch.Tensor([123.675, 116.28, 103.53]).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.Tensor([58.395, 57.12, 57.375]).view(-1, 1, 1), False)
+        lora_rank = int(config.LORA_RANK) if config.ENCODER_LORA else 0
+        self.image_encoder = _ImageEncoderParams(config.PATCH_SIZE, lora_rank=lora_rank, **arch)
+        self.map_decoder = nn.Sequential(  # model.py:286-295 (indices 0,1,3,5,7 carry parameters)
+            nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2), _LayerNorm2dParams(128), nn.GELU(),
+            nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2), nn.GELU(),
+            nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2), nn.GELU(),
+            nn.ConvTranspose2d(32, 2, kernel_size=2, stride=2))
+        self.topo_net = _TopoNetParams(config.TOPONET_VERSION)
+        self._packed = {}  # device index -> (Context, weights handle)
+        self._init_from_sam_checkpoint()
+
+    # ---- init-time SAM checkpoint (model.py:365-411) ------------------------------------------------------
+    def _init_from_sam_checkpoint(self):
+        path = self.config.SAM_CKPT_PATH
+        if not path or not os.path.exists(str(path)):
+            warnings.warn(f"SAM checkpoint {path!r} not found: skipping the SAM initialisation that the "
+                          "reference performs unconditionally (model.py:367); load a fine-tuned state_dict instead")
+            return
+        ckpt = torch.load(path, map_location="cpu")
+        grid = self.image_size // 16
+        if self.image_size != 1024 and ckpt["image_encoder.pos_embed"].shape[1] != grid:
+            ckpt = dict(ckpt)
+            pe = ckpt["image_encoder.pos_embed"].permute(0, 3, 1, 2)
+            pe = nn.functional.interpolate(pe, (grid, grid), mode="bilinear", align_corners=False)
+            ckpt["image_encoder.pos_embed"] = pe.permute(0, 2, 3, 1)
+            # the reference selects "global" rel-pos keys by substring match on the block index
+            # (model.py:403), which also catches e.g. block 17 for index 7 — reproduced as is.
+            for k in [k for k in ckpt if "rel_pos" in k and any(str(i) in k for i in self.arch["global_attn_indexes"])]:
+                t = ckpt[k][None, None]
+                ckpt[k] = nn.functional.interpolate(t, (grid * 2 - 1, t.shape[-1]), mode="bilinear",
+                                                    align_corners=False)[0, 0]
+        own = dict(self.named_parameters())
+        matched = {k: v for k, v in ckpt.items() if k in own and own[k].shape == v.shape}
+        self.matched_param_names = set(matched)
+        self.load_state_dict(matched, strict=False)
+
+    # ---- packed weights life cycle ------------------------------------------------------------------------
+    def _invalidate(self):
+        for ctx, handle in self._packed.values():
+            ctx.lib.srh_weights_free(handle)
+        self._packed = {}
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
+
+    def __del__(self):
+        try:
+            self._invalidate()
+        except Exception:
+            pass
+
+    def _weights(self, device):
+        if device.type != "cuda":
+            raise _lib.SrhError("SAMRoad runs on an MI355X only (tensor is on %s); there is no CPU fallback" % device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        hit = self._packed.get(idx)
+        if hit is not None:
+            return hit
+        ctx = _lib.Context.get(idx)
+        sd = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in self.state_dict().items()}
+        # fold LoRA adapters into the fused qkv weight (q rows [0:D], v rows [2D:3D]; model.py:179-185)
+        for k in [k for k in sd if k.endswith("attn.qkv.linear_a_q.weight")]:
+            base = k[: -len("linear_a_q.weight")]
+            w = sd[base + "weight"].clone()
+            d = w.shape[1]
+            w[:d] += sd[base + "linear_b_q.weight"] @ sd[base + "linear_a_q.weight"]
+            w[2 * d:] += sd[base + "linear_b_v.weight"] @ sd[base + "linear_a_v.weight"]
+            sd[base + "weight"] = w
+        cfg = _lib.ModelCfg()
+        cfg.embed_dim, cfg.depth, cfg.num_heads = self.arch["embed_dim"], self.arch["depth"], self.arch["num_heads"]
+        cfg.patch_size = int(self.config.PATCH_SIZE)
+        gi = list(self.arch["global_attn_indexes"])
+        cfg.n_global = len(gi)
+        for i, g in enumerate(gi):
+            cfg.global_attn_indexes[i] = g
+        cfg.window_size = 14
+        cfg.toponet_version = {"no_offset": 1, "no_transformer": 2}.get(self.config.TOPONET_VERSION, 0)
+        names = [k for k in sd if ".linear_" not in k]
+        arr = (_lib.NamedTensor * len(names))()
+        keep = []
+        for i, k in enumerate(names):
+            t = sd[k]
+            keep.append(k.encode())
+            arr[i].name = keep[-1]
+            arr[i].data = t.data_ptr()
+            arr[i].on_device = 0
+            arr[i].ndim = t.dim()
+            for j, s in enumerate(t.shape):
+                arr[i].shape[j] = s
+        handle = C.c_void_p()
+        ctx.check(ctx.lib.srh_weights_pack(ctx.handle, C.byref(cfg), arr, len(names), C.byref(handle)),
+                  "srh_weights_pack")
+        self._packed[idx] = (ctx, handle)
+        return self._packed[idx]
+
+    # ---- entry points -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _stream(device):
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _encode(self, rgb, want_logits, want_scores):
+        if rgb.dim() != 4 or rgb.shape[-1] != 3 or rgb.shape[1] != self.image_size or rgb.shape[2] != self.image_size:
+            raise ValueError(f"rgb must be [B,{self.image_size},{self.image_size},3], got {tuple(rgb.shape)}")
+        ctx, wh = self._weights(rgb.device)
+        if rgb.dtype == torch.uint8:
+            dt = _lib.SRH_U8
+        else:
+            rgb = rgb.to(torch.float32)
+            dt = _lib.SRH_F32
+        rgb = rgb.contiguous()
+        B, P = rgb.shape[0], self.image_size
+        h = P // 16
+        emb = torch.empty((B, h, h, 256), dtype=torch.float32, device=rgb.device)
+        logits = torch.empty((B, P, P, 2), dtype=torch.float32, device=rgb.device) if want_logits else None
+        scores = torch.empty((B, P, P, 2), dtype=torch.float32, device=rgb.device) if want_scores else None
+        with torch.cuda.device(rgb.device):
+            ctx.check(ctx.lib.srh_encode_decode(
+                ctx.handle, wh, rgb.data_ptr(), dt, B,
+                logits.data_ptr() if want_logits else None, scores.data_ptr() if want_scores else None,
+                emb.data_ptr(), self._stream(rgb.device)), "srh_encode_decode")
+        # reference shape [B,256,h,w]; memory stays channels-last (a permuted view, no copy)
+        return logits, scores, emb.permute(0, 3, 1, 2)
+
+    def _topo(self, image_embeddings, graph_points, pairs, valid, want_logits):
+        dev = image_embeddings.device
+        ctx, wh = self._weights(dev)
+        emb = image_embeddings.permute(0, 2, 3, 1)
+        if emb.dtype != torch.float32 or not emb.is_contiguous():
+            emb = emb.to(torch.float32).contiguous()
+        B, Ns, K = pairs.shape[0], pairs.shape[1], pairs.shape[2]
+        N = graph_points.shape[1]
+        if graph_points.dtype == torch.int64:
+            pts, pdt = graph_points.contiguous(), _lib.SRH_I64
+        else:
+            pts, pdt = graph_points.to(torch.float32).contiguous(), _lib.SRH_F32
+        if pairs.dtype == torch.int64:
+            prs, qdt = pairs.contiguous(), _lib.SRH_I64
+        else:
+            prs, qdt = pairs.to(torch.int32).contiguous(), _lib.SRH_I32
+        vld = valid.to(torch.uint8).contiguous()
+        scores = torch.empty((B, Ns, K, 1), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, Ns, K, 1), dtype=torch.float32, device=dev) if want_logits else None
+        if B * Ns * K > 0:
+            with torch.cuda.device(dev):
+                ctx.check(ctx.lib.srh_toponet(
+                    ctx.handle, wh, emb.data_ptr(), pts.data_ptr(), pdt, prs.data_ptr(), qdt, vld.data_ptr(),
+                    B, N, Ns, K, logits.data_ptr() if want_logits else None, scores.data_ptr(),
+                    self._stream(dev)), "srh_toponet")
+        return logits, scores
+
+    @torch.no_grad()
+    def forward(self, rgb, graph_points, pairs, valid):
+        mask_logits, mask_scores, emb = self._encode(rgb, True, True)
+        topo_logits, topo_scores = self._topo(emb, graph_points, pairs, valid, True)
+        return mask_logits, mask_scores, topo_logits, topo_scores
+
+    @torch.no_grad()
+    def infer_masks_and_img_features(self, rgb):
+        _, mask_scores, emb = self._encode(rgb, False, True)
+        return mask_scores, emb
+
+    @torch.no_grad()
+    def infer_toponet(self, image_embeddings, graph_points, pairs, valid):
+        return self._topo(image_embeddings, graph_points, pairs, valid, False)[1]

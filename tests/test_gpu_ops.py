@@ -1,0 +1,155 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 on the same
+fp16-representable inputs.  Run on an MI355X: pytest -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sam_road_amd import _lib
+    assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
+    return _lib.Context.get(0)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,act,resid", [(256, 128, 64, 0, False), (300, 256, 192, 1, False),
+                                              (1000, 768, 768, 0, True), (128, 384, 3072, 2, False)])
+def test_gemm(ctx, M, N, K, act, resid):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) * 0.05).half()
+    # asymmetric structure so a transposed C-write cannot pass
+    A[:, 0] += torch.arange(M).half() * 0.01
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g) if resid else None
+    ref = A.float() @ W.float().t() + bias
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    if resid:
+        ref = ref + R
+    dA, dW, db = A.cuda(), W.cuda(), bias.cuda()
+    dR = R.cuda() if resid else None
+    o32 = torch.full((M, N), float("nan"), device="cuda")
+    o16 = torch.zeros((M, N), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(dA), _p(dW), _p(db), _p(dR), M, N, K, act, _p(o32), _p(o16), None),
+              "srh_op_gemm")
+    _sync()
+    err = (o32.cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-4 * max(scale, 1.0) * (K / 64) ** 0.5, (err, scale)
+    assert (o16.cpu().float() - ref).abs().max().item() <= 2e-3 * max(scale, 1.0)
+
+
+def test_gemm_inplace_residual(ctx):
+    M, N, K = 384, 256, 128
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) * 0.1).half()
+    X = torch.randn(M, N, generator=g)
+    ref = X + A.float() @ W.float().t()
+    dX, dA, dW = X.cuda(), A.cuda(), W.cuda()   # keep the device tensors alive across the async call
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(dA), _p(dW), None, _p(dX), M, N, K, 0, _p(dX), None, None),
+              "srh_op_gemm")
+    _sync()
+    assert (dX.cpu() - ref).abs().max().item() < 1e-3
+
+
+def test_conv3x3(ctx):
+    B, S, Cc, N = 2, 16, 128, 128
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, Cc, S, S, generator=g).half()
+    w = (torch.randn(N, Cc, 3, 3, generator=g) * 0.05).half()
+    ref = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1)          # [B,S,S,N]
+    a = x.permute(0, 2, 3, 1).contiguous().cuda()                                  # channels-last
+    wg = w.permute(0, 2, 3, 1).reshape(N, 9 * Cc).contiguous().cuda()              # k = tap*C + c
+    out = torch.zeros((B, S, S, N), device="cuda")
+    ctx.check(ctx.lib.srh_op_conv3x3(ctx.handle, _p(a), _p(wg), B, S, Cc, N, _p(out), None), "srh_op_conv3x3")
+    _sync()
+    assert (out.cpu() - ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("D,gelu", [(768, 0), (256, 0), (128, 1), (1024, 0), (1280, 0)])
+def test_layernorm(ctx, D, gelu):
+    M = 517
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g) * 3 + 1.5
+    gm, bt = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = F.layer_norm(x, (D,), gm, bt, 1e-6)
+    if gelu:
+        ref = F.gelu(ref)
+    o32 = torch.zeros((M, D), device="cuda")
+    o16 = torch.zeros((M, D), device="cuda", dtype=torch.half)
+    dx, dg, db = x.cuda(), gm.cuda(), bt.cuda()
+    ctx.check(ctx.lib.srh_op_layernorm(ctx.handle, _p(dx), _p(dg), _p(db), 1e-6, M, D, gelu,
+                                       _p(o32), _p(o16), None), "srh_op_layernorm")
+    _sync()
+    assert (o32.cpu() - ref).abs().max().item() < 2e-5
+    assert (o16.cpu().float() - ref).abs().max().item() < 5e-3
+    # cast-only mode
+    ctx.check(ctx.lib.srh_op_layernorm(ctx.handle, _p(dx), None, None, 0.0, M, D, 0, None, _p(o16), None),
+              "srh_op_layernorm(cast)")
+    _sync()
+    assert torch.equal(o16.cpu(), x.half())
+
+
+def ref_sam_attention(qkv, rel_h, rel_w, bias, B, S, heads, win):
+    """SURVEY App. B.2-B.4 on a fused qkv tensor [B,S,S,3D] (fp32 math): window partition with pad
+    tokens = qkv bias, decomposed rel-pos from the unscaled q, softmax, un-partition + crop."""
+    D = heads * 64
+    x = qkv.float().view(B, S, S, 3 * D)
+    if win < S:
+        pad = (win - S % win) % win
+        Sp = S + pad
+        full = bias.float().view(1, 1, 1, 3 * D).expand(B, Sp, Sp, 3 * D).clone()
+        full[:, :S, :S] = x
+        nw = Sp // win
+        xw = full.view(B, nw, win, nw, win, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(-1, win, win, 3 * D)
+    else:
+        xw, Sp, nw = x, S, 1
+    Bp = xw.shape[0]
+    q, k, v = xw.reshape(Bp, win * win, 3, heads, 64).permute(2, 0, 3, 1, 4).reshape(3, Bp * heads, win * win, 64).unbind(0)
+    attn = (q * 0.125) @ k.transpose(-2, -1)
+    idx = torch.arange(win)[:, None] - torch.arange(win)[None, :] + (win - 1)
+    Rh, Rw = rel_h.float()[idx], rel_w.float()[idx]
+    rq = q.reshape(-1, win, win, 64)
+    attn = (attn.view(-1, win, win, win, win) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[:, :, :, :, None]
+            + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(-1, win * win, win * win)
+    out = (attn.softmax(-1) @ v).view(Bp, heads, win, win, 64).permute(0, 2, 3, 1, 4).reshape(Bp, win, win, D)
+    if win < S:
+        out = out.view(B, nw, nw, win, win, D).permute(0, 1, 3, 2, 4, 5).reshape(B, Sp, Sp, D)[:, :S, :S]
+    return out.reshape(B * S * S, D)
+
+
+@pytest.mark.parametrize("S,win", [(32, 14), (32, 32), (16, 14), (16, 16)])
+def test_sam_attention(ctx, S, win):
+    B, heads = 2, 3
+    D = heads * 64
+    g = torch.Generator().manual_seed(S * 100 + win)
+    qkv = (torch.randn(B * S * S, 3 * D, generator=g) * 1.5).half()
+    bias = (torch.randn(3 * D, generator=g) * 0.5).half()
+    rel_h = (torch.randn(2 * win - 1, 64, generator=g) * 0.3).half()
+    rel_w = (torch.randn(2 * win - 1, 64, generator=g) * 0.3).half()
+    ref = ref_sam_attention(qkv, rel_h, rel_w, bias, B, S, heads, win)
+    out = torch.zeros((B * S * S, D), device="cuda", dtype=torch.half)
+    dq, dh, dw, db = qkv.cuda(), rel_h.cuda(), rel_w.cuda(), bias.cuda()
+    ctx.check(ctx.lib.srh_op_attention(ctx.handle, _p(dq), _p(dh), _p(dw), _p(db),
+                                       B, S, heads, win, _p(out), None), "srh_op_attention")
+    _sync()
+    err = (out.cpu().float() - ref).abs()
+    assert torch.isfinite(out.cpu().float()).all()
+    assert err.max().item() < 2e-2 and err.mean().item() < 1.5e-3, (err.max().item(), err.mean().item())

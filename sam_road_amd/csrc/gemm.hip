@@ -4,8 +4,9 @@
 // Replaces the ATen call sites K2/K4/K7/K8/K9/K10/K13 of SURVEY.md §2.1 (nn.Linear / 1x1 and
 // 3x3 Conv2d / ConvTranspose2d-as-GEMM in the un-vendored SAM fork and reference model.py:283-295).
 //
-// Design (gfx950): 128x128x64 block tile, 256 threads = 4 waves in a 2(N) x 2(M) grid, each wave
-// 64x64 via 2x2 v_mfma_f32_32x32x16_f16 tiles (64 accumulator registers).  The MFMA is issued
+// Design (gfx950): 256x256x64 block tile (512 threads = 8 waves as 4(N) x 2(M), each wave 64x128 via
+// 2x4 v_mfma_f32_32x32x16_f16 tiles = 128 accumulator registers, 128 KiB LDS, one workgroup per CU)
+// for the large layers; a 128x128x64 / 4-wave variant for thin problems (N % 256 != 0).  The MFMA is issued
 // "transposed" (A operand = weight rows, B operand = activation rows) so that every lane ends up
 // with 4 CONSECUTIVE output columns of one output row: the epilogue then does 16-byte bias /
 // residual loads and 8/16-byte stores instead of 2-byte scatters.  Operands are staged
@@ -13,13 +14,22 @@
 // tile k) with a 16-byte-chunk XOR swizzle so the ds_read_b128 fragment reads are conflict-free.
 #include "common.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace srh {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int GEMM_THREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
-constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;     // 64 KiB
+constexpr int BK = 64;
+
+// fast exact-GELU: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 rounding
+// of the stored activation); ~15 VALU ops per element instead of erff's ~40.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    const float erf_v = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf_v);
+}
 
 // Source row for the activation operand.  AMODE 0: plain row m.  AMODE 1: implicit 3x3 conv over
 // an [B,S,S,C] channels-last grid (zero padding 1): k-tile kt addresses tap = (kt*BK)/C.
@@ -40,91 +50,19 @@ __device__ __forceinline__ const f16* a_src(const GemmParams& p, int m, int kt, 
     }
 }
 
-template <int AMODE>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
-    const int tiles_n = p.N / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.K / BK;
-
-    // staging assignment: 4 chunks of A and 4 of W per thread per k-tile
-    uint4 ra[4], rw[4];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + GEMM_THREADS * i;
-            const int row = id >> 3, c = id & 7;
-            int m = m0 + row;
-            if (m >= p.M) m = p.M - 1;
-            bool zero;
-            const f16* src = a_src<AMODE>(p, m, kt, zero);
-            ra[i] = zero ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(src + c * 8);
-            rw[i] = *reinterpret_cast<const uint4*>(p.W + (size_t)(n0 + row) * p.ldw + kt * BK + c * 8);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * 2 * TILE_BYTES;
-        char* sw = sa + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + GEMM_THREADS * i;
-            const int row = id >> 3, c = id & 7;
-            const int off = row * 128 + swz8(row, c) * 16;
-            *reinterpret_cast<uint4*>(sa + off) = ra[i];
-            *reinterpret_cast<uint4*>(sw + off) = rw[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
+// Epilogue shared by the GEMM kernels: lane holds, per (i,j,q), 4 consecutive columns n..n+3 of row m.
+template <int TN, int TM>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mw, int nw, int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char* sa = smem + stage * 2 * TILE_BYTES;
-        const char* sw = sa + TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f16x8 fw[2], fx[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rw_ = wn * 64 + i * 32 + frow;
-                fw[i] = *reinterpret_cast<const f16x8*>(sw + rw_ * 128 + swz8(rw_, ks * 2 + fhalf) * 16);
-                const int rx_ = wm * 64 + i * 32 + frow;
-                fx[i] = *reinterpret_cast<const f16x8*>(sa + rx_ * 128 + swz8(rx_, ks * 2 + fhalf) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]);
-        }
-        if (kt + 1 < nk) store_tile(stage ^ 1);
-        __syncthreads();
-    }
-
-    // epilogue: lane holds, per (i,j,q), 4 consecutive columns n..n+3 of row m
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wm * 64 + j * 32 + frow;
+    for (int j = 0; j < TM; ++j) {
+        const int m = mw + j * 32 + frow;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TN; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * fhalf;
+                const int n = nw + i * 32 + 8 * q + 4 * fhalf;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
@@ -134,7 +72,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
                 }
                 if (p.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 } else if (p.act == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -158,21 +96,413 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     }
 }
 
-int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0) return 0;
-    if (p.N % BN != 0 || p.K % BK != 0) return -2;
-    if (p.conv_S > 0 && (p.conv_C % BK != 0)) return -2;
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+// LDS-staged epilogue for a 64x64 wave tile (acc[2][2]): the accumulators (lane = one row, 4 consecutive
+// columns) are transposed through a wave-private 16 KiB f32 region [64 rows][16 chunks of 16 B], chunk index
+// XOR-swizzled with the row so both the b128 writes (8-lane groups = 8 rows, same column) and the b128
+// reads (16 lanes = one row) are conflict-free.  On read-back 16 consecutive lanes own one 256-byte row
+// segment, so bias / pos / residual loads and the f32 / f16 stores are full-line coalesced (the direct
+// form wrote 32 different rows per instruction, 16 B each).
+template <int TM, int J0>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&acc)[2][TM], char* wbuf,
+                                                int mw, int nw, int lane) {
+    const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 32 + frow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = i * 8 + 2 * q + fhalf;          // 16-byte chunk (4 columns) inside the 64-col row
+                const f32x4 v = {acc[i][J0 + j][4 * q], acc[i][J0 + j][4 * q + 1], acc[i][J0 + j][4 * q + 2], acc[i][J0 + j][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(wbuf + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane & 15, rsub = lane >> 4;
+    const int n = nw + c * 4;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int r = pass * 4 + rsub;
+        const int m = mw + r;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(wbuf + r * 256 + ((c ^ (r & 15)) << 4));
+        if (m >= p.M) continue;
+        float v[4] = {t[0] + bias.x, t[1] + bias.y, t[2] + bias.z, t[3] + bias.w};
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.pos) {
+            const float4 b = *reinterpret_cast<const float4*>(p.pos + (size_t)(m % p.pos_rows) * p.N + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.resid) {
+            const float4 b = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.out_f32)
+            *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.out_f16) {
+            f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h;
+        }
+    }
+}
+
+// XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed dispatch, speed only): give each XCD a
+// contiguous run of tiles, ordered in groups of GM tile rows with the column index outer, so the
+// workgroups resident on one XCD share a few A panels and W panels that fit its 4 MiB L2.
+template <int GM>
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int group = t / (GM * tiles_n), within = t - group * GM * tiles_n;
+    const int first_m = group * GM, gsz = min(GM, tiles_m - first_m);
+    tile_m = first_m + within % gsz;
+    tile_n = within / gsz;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant (plain row-major A): 128x128x64 tile, 4 waves, operands go HBM/L2 -> LDS directly with
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass).  The DMA destination is
+// wave-uniform base + lane*16, i.e. linear; the XOR swizzle the fragment reads need is applied to the
+// per-lane SOURCE address instead (lane (row, physical chunk pc) fetches logical chunk pc ^ key(row)).
+// Double-buffered: the DMA of k-tile t+1 is in flight while the MFMAs of k-tile t run; one barrier per
+// k-tile (whose wait also retires this wave's DMA).
+// ---------------------------------------------------------------------------------------------------
+template <int ABL, int NST>   // ABL ablation aid: 0 normal, 1 no DMA inside the k-loop, 2 no fragment reads / MFMA
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NST == 1 ? 4 : 2, NST == 1 ? 4 : 2)))
+void gemm_glds_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 128, TILE = BM * BK * 2, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K / BK;
+
+    // DMA piece i (0..3) of a wave covers rows i*32 + wave*8 .. +8 of the tile, 8 rows x 128 B = 1 KiB
+    const int prow = lane >> 3, pc = lane & 7;
+    const char* asrc[4];
+    const char* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 32 + wave * 8 + prow;
+        const int c = pc ^ ((r >> 1) & 7);
+        asrc[i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8);
+        wsrc[i] = reinterpret_cast<const char*>(p.W + (size_t)(n0 + r) * p.ldw + c * 8);
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+#define SRH_DMA_TILE(kt, stage) { \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+        char* d_ = smem + (stage) * STAGE + (i * 32 + wave * 8) * 128; \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)(kt) * (BK * 2)), (lds_ptr)d_, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc[i] + (size_t)(kt) * (BK * 2)), (lds_ptr)(d_ + TILE), 16, 0, 0); } }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * 64) * 128, x_row0 = (wm * 64) * 128;
+
+    if (NST == 2) SRH_DMA_TILE(0, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = NST == 2 ? (kt & 1) : 0;
+        if (NST == 1) {
+            if (kt > 0) __syncthreads();           // everyone finished reading the single stage
+            SRH_DMA_TILE(kt, 0)
+            __syncthreads();                       // vmcnt(0) + barrier: the tile has landed
+        } else {
+            __syncthreads();   // retires this wave's DMA (vmcnt(0)) and orders everyone's; frees stage^1
+            if (ABL != 1 && kt + 1 < nk) SRH_DMA_TILE(kt + 1, stage ^ 1)
+        }
+        if (ABL == 2) continue;
+        const char* sa = smem + stage * STAGE + x_row0;
+        const char* sw = smem + stage * STAGE + TILE + w_row0;
+        f16x8 fwA[2], fxA[2], fwB[2], fxB[2];
+#define SRH_FRAG2(fw, fx, ks) { fw[0] = *reinterpret_cast<const f16x8*>(sw + foff[ks]); \
+        fw[1] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + 4096); \
+        fx[0] = *reinterpret_cast<const f16x8*>(sa + foff[ks]); \
+        fx[1] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + 4096); }
+#define SRH_MMA2(fw, fx) { acc[0][0] = mfma32(fw[0], fx[0], acc[0][0]); acc[0][1] = mfma32(fw[0], fx[1], acc[0][1]); \
+        acc[1][0] = mfma32(fw[1], fx[0], acc[1][0]); acc[1][1] = mfma32(fw[1], fx[1], acc[1][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG2(fwA, fxA, 0)
+        SRH_FRAG2(fwB, fxB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA2(fwA, fxA)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG2(fwA, fxA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA2(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG2(fwB, fxB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA2(fwA, fxA)
+        SRH_MMA2(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NST == 1) { epilogue<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane); return; }
+    __syncthreads();   // every wave is done reading operand tiles: LDS becomes epilogue staging space
+    epilogue_staged<2, 0>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256x256x64 LDS-DMA variant: 512 threads = 8 waves as 4(N) x 2(M), wave tile 64(N) x 128(M) = 2x4 MFMA
+// tiles (128 accumulator registers), 2 x 64 KiB LDS stages, one workgroup per CU.  Half the L2->LDS bytes
+// per FLOP of the 128x128 tile and 0.75 ds_read_b128 per MFMA instead of 1.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_glds256_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, TILE = BM * BK * 2, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block<4>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K / BK;
+
+    // DMA piece i (0..3) of a wave covers rows i*64 + wave*8 .. +8 of the 256-row tile
+    const int prow = lane >> 3, pc = lane & 7;
+    const char* asrc[4];
+    const char* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 64 + wave * 8 + prow;
+        const int c = pc ^ ((r >> 1) & 7);
+        asrc[i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8);
+        wsrc[i] = reinterpret_cast<const char*>(p.W + (size_t)(n0 + r) * p.ldw + c * 8);
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+#define SRH_DMA_TILE256(kt, stage) { \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+        char* d_ = smem + (stage) * STAGE + (i * 64 + wave * 8) * 128; \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)(kt) * (BK * 2)), (lds_ptr)d_, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc[i] + (size_t)(kt) * (BK * 2)), (lds_ptr)(d_ + TILE), 16, 0, 0); } }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * 64) * 128, x_row0 = (wm * 128) * 128;
+
+    SRH_DMA_TILE256(0, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        __syncthreads();
+        if (kt + 1 < nk) SRH_DMA_TILE256(kt + 1, stage ^ 1)
+        const char* sa = smem + stage * STAGE + x_row0;
+        const char* sw = smem + stage * STAGE + TILE + w_row0;
+        f16x8 fwA[2], fxA[4], fwB[2], fxB[4];
+#define SRH_FRAG4(fw, fx, ks) { fw[0] = *reinterpret_cast<const f16x8*>(sw + foff[ks]); \
+        fw[1] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + 4096); \
+        fx[0] = *reinterpret_cast<const f16x8*>(sa + foff[ks]); fx[1] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + 4096); \
+        fx[2] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + 8192); fx[3] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + 12288); }
+#define SRH_MMA4(fw, fx) { \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]); }
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG4(fwA, fxA, 0)
+        SRH_FRAG4(fwB, fxB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA4(fwA, fxA)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG4(fwA, fxA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA4(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG4(fwB, fxB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA4(fwA, fxA)
+        SRH_MMA4(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+    __builtin_amdgcn_wave_barrier();
+    epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + wm * 128 + 64, n0 + wn * 64, lane);
+}
+
+// Tile configuration: WN x WM waves, each wave TN x TM MFMA tiles of 32x32 (N = weight rows, M = activation rows)
+//   small: 2x2 waves, 2x2 tiles -> 128x128, 256 threads, 64 KiB LDS, 2 workgroups / CU
+//   big:   4x2 waves, 2x4 tiles -> 256(N) x 256(M), 512 threads, 128 KiB LDS, 1 workgroup / CU
+template <int AMODE, int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(WN * WM * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_kernel(GemmParams p) {
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, THREADS = WN * WM * 64;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int RSTRIDE = THREADS / 8;                 // rows between a thread's staged chunks
+    constexpr int NA = BM / RSTRIDE, NW = BN / RSTRIDE;  // chunks per thread per operand (4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    int tile_m, tile_n;
+    tile_of_block<(BM == 128 ? 8 : 4)>(tiles_m, tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K / BK;
+
+    // staging: thread owns 16-byte chunk `cch` of rows srow + RSTRIDE*i (i < 4) of both operands.  Named
+    // registers, not arrays: hipcc keeps `uint4 r[4]` staging arrays in scratch memory here.
+    static_assert(NA == 4 && NW == 4, "staging code assumes 4 chunks per thread per operand");
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    const int srow = tid >> 3, cch = tid & 7;
+    const int am0 = min(m0 + srow, p.M - 1), am1 = min(m0 + srow + RSTRIDE, p.M - 1);
+    const int am2 = min(m0 + srow + 2 * RSTRIDE, p.M - 1), am3 = min(m0 + srow + 3 * RSTRIDE, p.M - 1);
+    const f16* wbase = p.W + (size_t)(n0 + srow) * p.ldw + cch * 8;
+    const int soff = srow * 128 + swz8(srow, cch) * 16;   // RSTRIDE is a multiple of 16: same swizzle key
+
+#define SRH_LOAD_A(dst, am, kt) { bool z_; const f16* s_ = a_src<AMODE>(p, am, (kt), z_); \
+        dst = *reinterpret_cast<const uint4*>(s_ + cch * 8);   /* always a valid address: load, then select */ \
+        if (AMODE != 0) { dst.x = z_ ? 0u : dst.x; dst.y = z_ ? 0u : dst.y; dst.z = z_ ? 0u : dst.z; dst.w = z_ ? 0u : dst.w; } }
+#define SRH_LOAD_TILE(kt) { SRH_LOAD_A(ra0, am0, kt) SRH_LOAD_A(ra1, am1, kt) SRH_LOAD_A(ra2, am2, kt) SRH_LOAD_A(ra3, am3, kt) \
+        rw0 = *reinterpret_cast<const uint4*>(wbase + (size_t)(kt) * BK); \
+        rw1 = *reinterpret_cast<const uint4*>(wbase + (size_t)(RSTRIDE) * p.ldw + (size_t)(kt) * BK); \
+        rw2 = *reinterpret_cast<const uint4*>(wbase + (size_t)(2 * RSTRIDE) * p.ldw + (size_t)(kt) * BK); \
+        rw3 = *reinterpret_cast<const uint4*>(wbase + (size_t)(3 * RSTRIDE) * p.ldw + (size_t)(kt) * BK); }
+#define SRH_STORE_TILE(stage) { char* sa_ = smem + (stage) * STAGE + soff; char* sw_ = sa_ + A_BYTES; \
+        *reinterpret_cast<uint4*>(sa_) = ra0; *reinterpret_cast<uint4*>(sw_) = rw0; \
+        *reinterpret_cast<uint4*>(sa_ + RSTRIDE * 128) = ra1; *reinterpret_cast<uint4*>(sw_ + RSTRIDE * 128) = rw1; \
+        *reinterpret_cast<uint4*>(sa_ + RSTRIDE * 256) = ra2; *reinterpret_cast<uint4*>(sw_ + RSTRIDE * 256) = rw2; \
+        *reinterpret_cast<uint4*>(sa_ + RSTRIDE * 384) = ra3; *reinterpret_cast<uint4*>(sw_ + RSTRIDE * 384) = rw3; }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    SRH_LOAD_TILE(0)
+    SRH_STORE_TILE(0)
+    __syncthreads();
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // fragment byte offsets inside a tile: row r, k-step ks -> r*128 + swz8(r, 2ks+half)*16; every row this
+    // lane reads is frow + 32*j, so the swizzle key ((row>>1)&7) is the lane's own.
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * TN * 32) * 128, x_row0 = (wm * TM * 32) * 128;
+
+#define SRH_FRAG(fw, fx, ks) { \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + 4096 * i); \
+    _Pragma("unroll") for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + 4096 * j); }
+#define SRH_MMA(fw, fx) { \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i) \
+    _Pragma("unroll") for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]); }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        const int ktn = kt + 1 < nk ? kt + 1 : kt;    // last iteration re-loads its own tile (no branch)
+        SRH_LOAD_TILE(ktn)
+        const char* sa = smem + stage * STAGE + x_row0;
+        const char* sw = smem + stage * STAGE + A_BYTES + w_row0;
+        f16x8 fwA[TN], fxA[TM], fwB[TN], fxB[TM];
+        // Order pinned with sched_barrier: hipcc otherwise sinks the global loads below the MFMAs (to
+        // the ds_write that consumes them), exposing the full memory latency every k-tile, and collapses
+        // the fragment double-buffering.
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG(fwA, fxA, 0)
+        SRH_FRAG(fwB, fxB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA(fwA, fxA)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG(fwA, fxA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG(fwB, fxB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA(fwA, fxA)
+        SRH_MMA(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_STORE_TILE(stage ^ 1)
+        __syncthreads();
+    }
+
+    epilogue<TN, TM>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+}
+
+template <int AMODE, int WN, int WM, int TN, int TM>
+static int launch_cfg(const GemmParams& p, hipStream_t stream) {
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, THREADS = WN * WM * 64;
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
     static bool attr_set = false;
+    auto kern = gemm_kernel<AMODE, WN, WM, TN, TM>;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    if (p.conv_S > 0)
-        hipLaunchKernelGGL(gemm_kernel<1>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, stream, p);
-    else
-        hipLaunchKernelGGL(gemm_kernel<0>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, stream, p);
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    if (p.N % 128 != 0 || p.K % BK != 0) return -2;
+    if (p.conv_S > 0 && (p.conv_C % BK != 0)) return -2;
+    if (p.conv_S > 0) return launch_cfg<1, 2, 2, 2, 2>(p, stream);
+    static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;   // tuning aid
+    const int variant = p.variant ? p.variant : env_variant;
+    if (variant == 1) return launch_cfg<0, 2, 2, 2, 2>(p, stream);
+    if (variant == 2 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<0, 4, 2, 2, 4>(p, stream);
+    if (false) return (p.N % 256 == 0) ? launch_cfg<0, 4, 2, 2, 4>(p, stream) : -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set = true;
+    }
+    // 256x256 tiles halve the L2->LDS traffic per FLOP but there are only 256 CUs: use them when the tile
+    // count fills the chip evenly (<= one round, or >= 80 % occupancy of the last round), else 128x128.
+    const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
+    const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
+    if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && fits256) {
+        hipLaunchKernelGGL(gemm_glds256_kernel, dim3(((p.M + 255) / 256) * (p.N / 256)), dim3(512), 131072, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    const int grid = ((p.M + 127) / 128) * (p.N / 128);
+    if (variant == 11) hipLaunchKernelGGL((gemm_glds_kernel<1, 2>), dim3(grid), dim3(256), 65536, stream, p);
+    else if (variant == 12) hipLaunchKernelGGL((gemm_glds_kernel<2, 2>), dim3(grid), dim3(256), 65536, stream, p);
+    else if (variant == 4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1>), dim3(grid), dim3(256), 65536 / 2, stream, p);
+    else hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid), dim3(256), 65536, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

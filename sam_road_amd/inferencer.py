@@ -1,0 +1,168 @@
+"""Scene-level tiled inference (reference inferencer.py:61-234) on the HIP path.
+
+    infer_one_img(net, img, config) -> (pred_nodes[N,2] (row, col), pred_edges[E,2],
+                                        keypoint_mask u8[H,W], road_mask u8[H,W])
+
+Pass 1 (tile batcher, model, mask fusion, normalise) runs entirely on the GPU behind
+SAMRoad.scene_pass1 / scene_normalise: the u8 scene is uploaded ONCE (the reference ships 4x the
+bytes as f32 tiles, inferencer.py:56,94) and tiles are cropped on the device.  The step between the
+passes (mask -> points) and the pass-2 query builder / edge vote stay on the host as in the
+reference (SURVEY.md §8f "next" rows), with the python triple loop replaced by numpy.
+
+With torch.distributed initialised (one process per GPU) the tile list is split into contiguous
+chunks per rank; canvases are summed on rank 0, points broadcast, edge votes gathered
+(sam_road_amd/distributed.py).  Only rank 0 returns the graph; other ranks return None.
+"""
+import numpy as np
+import scipy.spatial
+import torch
+
+from . import distributed as D
+from .graph_points import extract_graph_points
+from .tiling import get_patch_info_one_img, shard_tiles
+
+
+def build_patch_queries(graph_points, x0, y0, x1, y1, config):
+    """inferencer.py:148-176 for one tile: closed-box point query (rtree.intersection semantics for
+    degenerate boxes), kNN(k+1) within NEIGHBOR_RADIUS, self removed, missing neighbour -> source."""
+    gx, gy = graph_points[:, 0], graph_points[:, 1]
+    ids = np.nonzero((gx >= x0) & (gx <= x1) & (gy >= y0) & (gy <= y1))[0]
+    n, k = len(ids), int(config.MAX_NEIGHBOR_QUERIES)
+    pts = graph_points[ids, :] - np.array([[x0, y0]], dtype=graph_points.dtype)
+    if n == 0:
+        return ids, pts.reshape(0, 2), np.zeros((0, k, 2), np.int64), np.zeros((0, k), bool)
+    tree = scipy.spatial.cKDTree(pts)
+    _, knn = tree.query(pts, k=k + 1, distance_upper_bound=config.NEIGHBOR_RADIUS)
+    knn = knn[:, 1:]
+    src = np.tile(np.arange(n)[:, None], (1, k))
+    valid = knn < n
+    tgt = np.where(valid, knn, src)
+    return ids, pts, np.stack([src, tgt], -1), valid
+
+
+def _collate(xs):
+    length = max(x.shape[0] for x in xs)
+    return np.stack([np.pad(x, [(0, length - x.shape[0])] + [(0, 0)] * (x.ndim - 1)) for x in xs], 0)
+
+
+def infer_one_img(net, img, config, device=None):
+    device = torch.device(device) if device is not None else next(net.parameters()).device
+    image_size = img.shape[0]
+    bs = int(config.INFER_BATCH_SIZE)
+    infos = get_patch_info_one_img(0, image_size, config.SAMPLE_MARGIN, config.PATCH_SIZE,
+                                   config.INFER_PATCHES_PER_EDGE)
+    all_xy = np.array([[p[1][0], p[1][1]] for p in infos], dtype=np.int32)
+    world = torch.distributed.get_world_size() if D.is_distributed() else 1
+    rank = torch.distributed.get_rank() if D.is_distributed() else 0
+    lo, hi = shard_tiles(len(infos), world, rank)
+
+    # ---- pass 1 (GPU): crop -> encoder -> decoder -> fused canvases; embeddings stay resident
+    scene = torch.as_tensor(np.ascontiguousarray(img), dtype=torch.uint8).to(device)
+    xy_dev = torch.as_tensor(all_xy).to(device)
+    kp_c, road_c, emb = net.scene_pass1(scene, xy_dev[lo:hi], bs)
+    D.reduce_canvases(kp_c, road_c, dst=0)
+    graph_points = None
+    kp_mask = road_mask = None
+    if rank == 0:
+        kp_u8, road_u8 = net.scene_normalise(kp_c, road_c, xy_dev)
+        kp_mask, road_mask = kp_u8.cpu().numpy(), road_u8.cpu().numpy()
+        graph_points = extract_graph_points(kp_mask, road_mask, config)
+    graph_points = D.broadcast_points(graph_points, src=0, device=device if world > 1 else None)
+    if graph_points.shape[0] == 0:
+        if rank != 0:
+            return None
+        return graph_points, np.zeros((0, 2), dtype=np.int32), kp_mask, road_mask
+
+    # ---- pass 2: per-tile queries (host) -> sampler + TopoNet (GPU) -> directed edge votes
+    n_pts = graph_points.shape[0]
+    keys_l, score_l = [], []
+    for off in range(lo, hi, bs):
+        end = min(off + bs, hi)
+        qs = [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(off, end)]
+        pts, pairs, valid = _collate([q[1] for q in qs]), _collate([q[2] for q in qs]), _collate([q[3] for q in qs])
+        if pts.shape[1] == 0:
+            continue
+        scores = net.infer_toponet(emb[off - lo:end - lo], torch.as_tensor(pts).to(device),
+                                   torch.as_tensor(pairs).to(device), torch.as_tensor(valid).to(device))
+        scores = torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1).cpu().numpy()
+        for b, (ids, _, _, _) in enumerate(qs):
+            n = len(ids)
+            if n == 0:
+                continue
+            v = valid[b, :n]
+            src_all = ids[pairs[b, :n, :, 0]][v]
+            tgt_all = ids[pairs[b, :n, :, 1]][v]
+            sc = scores[b, :n][v]
+            assert ((sc >= 0.0) & (sc <= 1.0)).all()
+            keys_l.append(src_all.astype(np.int64) * n_pts + tgt_all.astype(np.int64))
+            score_l.append(sc.astype(np.float64))
+    if keys_l:
+        k = np.concatenate(keys_l); s = np.concatenate(score_l)
+        uk, inv = np.unique(k, return_inverse=True)
+        sums = np.zeros(uk.shape[0]); cnts = np.zeros(uk.shape[0])
+        np.add.at(sums, inv, s)
+        np.add.at(cnts, inv, 1.0)
+    else:
+        uk, sums, cnts = np.zeros(0, np.int64), np.zeros(0), np.zeros(0)
+    uk, sums, cnts = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None)
+    if rank != 0:
+        return None
+    keep = (sums / np.maximum(cnts, 1.0)) > config.TOPO_THRESHOLD
+    pred_edges = np.stack([uk[keep] // n_pts, uk[keep] % n_pts], axis=1).reshape(-1, 2)
+    pred_nodes = graph_points[:, ::-1]  # (row, col)
+    return pred_nodes, pred_edges, kp_mask, road_mask
+
+
+def main(argv=None):
+    """CLI with the reference's flags (inferencer.py:24-35).  Dataset enumeration, GT loading and the
+    cv2 visualisations of the reference's __main__ are outside the hot path; this entry point runs one
+    or more scene images given explicitly and writes masks (.npy/.png) + the sat2graph pickle."""
+    import argparse
+    import os
+    import pickle
+    import time
+    from .config import load_config
+    from .formats import convert_to_sat2graph_format
+    from .model import SAMRoad
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--checkpoint", default=None, help="checkpoint of the model to test.")
+    ap.add_argument("--config", default=None, help="model config.")
+    ap.add_argument("--output_dir", default=None)
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--images", nargs="*", default=[], help="scene images (.npy uint8 HxWx3 or PIL-readable)")
+    args = ap.parse_args(argv)
+    config = load_config(args.config)
+    net = SAMRoad(config)
+    ckpt = torch.load(args.checkpoint, map_location="cpu")
+    net.load_state_dict(ckpt["state_dict"], strict=True)
+    net.eval()
+    net.to(torch.device(args.device))
+    out_dir = os.path.join("save", args.output_dir or time.strftime("infer_%Y%m%d_%H%M%S"))
+    os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "graph"), exist_ok=True)
+    total = 0.0
+    for path in args.images:
+        if path.endswith(".npy"):
+            img = np.load(path)
+        else:
+            from PIL import Image
+            img = np.array(Image.open(path).convert("RGB"))
+        t0 = time.time()
+        res = infer_one_img(net, img, config)
+        total += time.time() - t0
+        if res is None:
+            continue
+        nodes, edges, kp, road = res
+        stem = os.path.splitext(os.path.basename(path))[0]
+        np.save(os.path.join(out_dir, "mask", f"{stem}_road.npy"), road)
+        np.save(os.path.join(out_dir, "mask", f"{stem}_itsc.npy"), kp)
+        if config.DATASET == "spacenet":
+            nodes = np.stack([400 - nodes[:, 0], nodes[:, 1]], axis=1)   # inferencer.py:332-334
+        with open(os.path.join(out_dir, "graph", f"{stem}.p"), "wb") as f:
+            pickle.dump(convert_to_sat2graph_format(nodes, edges), f)
+    with open(os.path.join(out_dir, "inference_time.txt"), "w") as f:
+        f.write(f"Inference completed for {args.config} in {total} seconds.")
+
+
+if __name__ == "__main__":
+    main()

@@ -300,3 +300,41 @@ class SAMRoad(nn.Module):
     @torch.no_grad()
     def infer_toponet(self, image_embeddings, graph_points, pairs, valid):
         return self._topo(image_embeddings, graph_points, pairs, valid, False)[1]
+
+    # ---- scene level (pass 1 of infer_one_img: tile batcher + model + mask fusion) -------------------------
+    @torch.no_grad()
+    def scene_pass1(self, scene_u8, tile_xy, batch_size, canvas_kp=None, canvas_road=None):
+        """scene_u8 [S,S,3] uint8 on the GPU, tile_xy int32 [n,2] (x0,y0) on the GPU.  Runs the tiles in
+        batches through the encoder + decoder and accumulates the two mask canvases in the reference's
+        sequential order (inferencer.py:87-104).  Returns (canvas_kp, canvas_road, embeddings[n,256,h,w])."""
+        dev = scene_u8.device
+        ctx, wh = self._weights(dev)
+        assert scene_u8.dtype == torch.uint8 and scene_u8.dim() == 3 and scene_u8.shape[2] == 3
+        scene_u8 = scene_u8.contiguous()
+        tile_xy = tile_xy.to(device=dev, dtype=torch.int32).contiguous()
+        S, n, h = scene_u8.shape[0], tile_xy.shape[0], self.image_size // 16
+        if canvas_kp is None:
+            canvas_kp = torch.zeros((S, S), dtype=torch.float32, device=dev)
+            canvas_road = torch.zeros((S, S), dtype=torch.float32, device=dev)
+        emb = torch.empty((n, h, h, 256), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ctx.check(ctx.lib.srh_scene_pass1(ctx.handle, wh, scene_u8.data_ptr(), S, tile_xy.data_ptr(), n,
+                                              int(batch_size), canvas_kp.data_ptr(), canvas_road.data_ptr(),
+                                              emb.data_ptr(), self._stream(dev)), "srh_scene_pass1")
+        return canvas_kp, canvas_road, emb.permute(0, 3, 1, 2)
+
+    @torch.no_grad()
+    def scene_normalise(self, canvas_kp, canvas_road, tile_xy):
+        """(canvas / coverage count) * 255 -> uint8 masks (inferencer.py:106-110); tile_xy = ALL tiles."""
+        dev = canvas_kp.device
+        ctx, _ = self._weights(dev)
+        S = canvas_kp.shape[0]
+        tile_xy = tile_xy.to(device=dev, dtype=torch.int32).contiguous()
+        kp = torch.empty((S, S), dtype=torch.uint8, device=dev)
+        road = torch.empty((S, S), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            ctx.check(ctx.lib.srh_scene_normalise(ctx.handle, canvas_kp.data_ptr(), canvas_road.data_ptr(), S,
+                                                  tile_xy.data_ptr(), tile_xy.shape[0], self.image_size,
+                                                  kp.data_ptr(), road.data_ptr(), self._stream(dev)),
+                      "srh_scene_normalise")
+        return kp, road

@@ -119,8 +119,8 @@ def vote_edges(votes, threshold):
     return np.array([e for e, s in sums.items() if s / cnts[e] > threshold]).reshape(-1, 2)
 
 
-def infer_one_img(net, img, config):
-    """inferencer.py:61-234 end-to-end on the CPU oracle ``net``."""
+def infer_pass1(net, img, config):
+    """inferencer.py:61-110: tile batches -> masks + cached features -> fused u8 masks."""
     size = img.shape[0]
     bs = config.INFER_BATCH_SIZE
     infos = get_patch_info_one_img(0, size, config.SAMPLE_MARGIN, config.PATCH_SIZE,
@@ -133,9 +133,13 @@ def infer_one_img(net, img, config):
         feats.append(f)
         scores.append(s)
     kp_mask, road_mask = fuse_masks(img.shape[:2], infos, scores)
-    points = extract_graph_points(kp_mask, road_mask, config)
-    if points.shape[0] == 0:
-        return points, np.zeros((0, 2), np.int32), kp_mask, road_mask
+    return infos, feats, kp_mask, road_mask
+
+
+def infer_pass2(net, feats, points, infos, config):
+    """inferencer.py:120-234: per-tile queries -> TopoNet -> directed edge votes -> thresholded edges."""
+    bs = config.INFER_BATCH_SIZE
+    nb = (len(infos) + bs - 1) // bs
     sums, cnts = defaultdict(float), defaultdict(float)
     for bi in range(nb):
         qs = [build_patch_queries(points, pi, config) for pi in infos[bi * bs:(bi + 1) * bs]]
@@ -155,5 +159,14 @@ def infer_one_img(net, img, config):
                     e = (int(ids[pairs[b, si, pi, 0]]), int(ids[pairs[b, si, pi, 1]]))
                     sums[e] += float(ts[b, si, pi])
                     cnts[e] += 1.0
-    edges = vote_edges((sums, cnts), config.TOPO_THRESHOLD)
+    return vote_edges((sums, cnts), config.TOPO_THRESHOLD), sums, cnts
+
+
+def infer_one_img(net, img, config):
+    """inferencer.py:61-234 end-to-end on the CPU oracle ``net``."""
+    infos, feats, kp_mask, road_mask = infer_pass1(net, img, config)
+    points = extract_graph_points(kp_mask, road_mask, config)
+    if points.shape[0] == 0:
+        return points, np.zeros((0, 2), np.int32), kp_mask, road_mask
+    edges, _, _ = infer_pass2(net, feats, points, infos, config)
     return points[:, ::-1], edges, kp_mask, road_mask

@@ -45,6 +45,44 @@ def _collate(xs):
     return np.stack([np.pad(x, [(0, length - x.shape[0])] + [(0, 0)] * (x.ndim - 1)) for x in xs], 0)
 
 
+def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
+    """Pass 2 over tiles [lo, hi) whose embeddings are emb[0 : hi-lo] (inferencer.py:135-221): returns the
+    unique directed edge keys (src * n_points + tgt) with their score sums and counts."""
+    bs = int(config.INFER_BATCH_SIZE)
+    n_pts = graph_points.shape[0]
+    keys_l, score_l = [], []
+    for off in range(lo, hi, bs):
+        end = min(off + bs, hi)
+        qs = [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(off, end)]
+        pts, pairs, valid = _collate([q[1] for q in qs]), _collate([q[2] for q in qs]), _collate([q[3] for q in qs])
+        if pts.shape[1] == 0:
+            continue
+        scores = net.infer_toponet(emb[off - lo:end - lo], torch.as_tensor(pts).to(device),
+                                   torch.as_tensor(pairs).to(device), torch.as_tensor(valid).to(device))
+        scores = torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1).cpu().numpy()
+        for b, (ids, _, _, _) in enumerate(qs):
+            n = len(ids)
+            if n == 0:
+                continue
+            v = valid[b, :n]
+            src_all = ids[pairs[b, :n, :, 0]][v]
+            tgt_all = ids[pairs[b, :n, :, 1]][v]
+            sc = scores[b, :n][v]
+            assert ((sc >= 0.0) & (sc <= 1.0)).all()
+            keys_l.append(src_all.astype(np.int64) * n_pts + tgt_all.astype(np.int64))
+            score_l.append(sc.astype(np.float64))
+    if not keys_l:
+        return np.zeros(0, np.int64), np.zeros(0), np.zeros(0)
+    k = np.concatenate(keys_l)
+    s = np.concatenate(score_l)
+    uk, inv = np.unique(k, return_inverse=True)
+    sums = np.zeros(uk.shape[0])
+    cnts = np.zeros(uk.shape[0])
+    np.add.at(sums, inv, s)
+    np.add.at(cnts, inv, 1.0)
+    return uk, sums, cnts
+
+
 def infer_one_img(net, img, config, device=None):
     device = torch.device(device) if device is not None else next(net.parameters()).device
     image_size = img.shape[0]
@@ -75,35 +113,7 @@ def infer_one_img(net, img, config, device=None):
 
     # ---- pass 2: per-tile queries (host) -> sampler + TopoNet (GPU) -> directed edge votes
     n_pts = graph_points.shape[0]
-    keys_l, score_l = [], []
-    for off in range(lo, hi, bs):
-        end = min(off + bs, hi)
-        qs = [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(off, end)]
-        pts, pairs, valid = _collate([q[1] for q in qs]), _collate([q[2] for q in qs]), _collate([q[3] for q in qs])
-        if pts.shape[1] == 0:
-            continue
-        scores = net.infer_toponet(emb[off - lo:end - lo], torch.as_tensor(pts).to(device),
-                                   torch.as_tensor(pairs).to(device), torch.as_tensor(valid).to(device))
-        scores = torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1).cpu().numpy()
-        for b, (ids, _, _, _) in enumerate(qs):
-            n = len(ids)
-            if n == 0:
-                continue
-            v = valid[b, :n]
-            src_all = ids[pairs[b, :n, :, 0]][v]
-            tgt_all = ids[pairs[b, :n, :, 1]][v]
-            sc = scores[b, :n][v]
-            assert ((sc >= 0.0) & (sc <= 1.0)).all()
-            keys_l.append(src_all.astype(np.int64) * n_pts + tgt_all.astype(np.int64))
-            score_l.append(sc.astype(np.float64))
-    if keys_l:
-        k = np.concatenate(keys_l); s = np.concatenate(score_l)
-        uk, inv = np.unique(k, return_inverse=True)
-        sums = np.zeros(uk.shape[0]); cnts = np.zeros(uk.shape[0])
-        np.add.at(sums, inv, s)
-        np.add.at(cnts, inv, 1.0)
-    else:
-        uk, sums, cnts = np.zeros(0, np.int64), np.zeros(0), np.zeros(0)
+    uk, sums, cnts = edge_votes(net, emb, graph_points, infos, lo, hi, config, device)
     uk, sums, cnts = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None)
     if rank != 0:
         return None

@@ -1,0 +1,158 @@
+"""CPU tests of the host-side mirror of the reference interface: config semantics, tile grid, mask->points,
+pass-2 query builder, output formats, SAMRoad state_dict layout, and that the C-ABI library loads and exports
+every symbol include/samroad_hip.h declares (no compute calls without a GPU)."""
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from sam_road_amd import Config, SAMRoad, get_patch_info_one_img, load_config
+from sam_road_amd import _lib
+from sam_road_amd.formats import convert_from_sat2graph_format, convert_to_sat2graph_format
+from sam_road_amd.graph_points import extract_graph_points, nms_points
+from sam_road_amd.inferencer import build_patch_queries
+from sam_road_amd.tiling import shard_tiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_missing_key_is_falsy(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text("SAM_VERSION: 'vit_h'\nPATCH_SIZE: 256\n")
+    cfg = load_config(str(p))
+    assert cfg.SAM_VERSION == "vit_h" and cfg.PATCH_SIZE == 256
+    assert not cfg.NO_SAM and not cfg.USE_SAM_DECODER          # reference utils.py:6-9 (addict) semantics
+    assert cfg.TOPONET_VERSION != "no_transformer"
+
+
+def test_patch_info_matches_reference_golden(golden_dir):
+    g = np.load(f"{golden_dir}/patch_info.npz")
+    i = 0
+    while f"case{i}" in g:
+        info = get_patch_info_one_img(0, *[int(v) for v in g[f"case{i}"]])
+        got = np.array([[p[1][0], p[1][1], p[2][0], p[2][1]] for p in info])
+        np.testing.assert_array_equal(got, g[f"xy{i}"])
+        i += 1
+    # CityScale: 256 tiles, origins 64..1472, x outer / y inner
+    info = get_patch_info_one_img(0, 2048, 64, 512, 16)
+    assert len(info) == 256 and info[0][1] == (64, 64) and info[1][1] == (64, 158) and info[-1][1] == (1472, 1472)
+
+
+def test_nms_points_matches_reference_golden(golden_dir):
+    g = np.load(f"{golden_dir}/nms_points.npz")
+    for i in range(4):
+        np.testing.assert_array_equal(nms_points(g[f"pts{i}"], g[f"sc{i}"], int(g[f"r{i}"])), g[f"kept{i}"])
+    np.testing.assert_array_equal(nms_points(g["pts_p"], g["sc_p"], 16), g["kept_p"])
+    assert nms_points(np.zeros((0, 2), np.int64), np.zeros((0,)), 8).shape == (0, 2)   # empty input
+
+
+def test_extract_graph_points_and_queries():
+    rng = np.random.default_rng(0)
+    kp = (rng.random((256, 256)) ** 8 * 255).astype(np.uint8)
+    road = (rng.random((256, 256)) ** 4 * 255).astype(np.uint8)
+    cfg = Config(ITSC_THRESHOLD=0.5, ROAD_THRESHOLD=0.6, ITSC_NMS_RADIUS=8, ROAD_NMS_RADIUS=16,
+                 NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16)
+    pts = extract_graph_points(kp, road, cfg)
+    from oracle import scene as oscene
+    from oracle.samroad import AttrDict
+    np.testing.assert_array_equal(pts, oscene.extract_graph_points(kp, road, AttrDict(cfg)))
+    d = np.linalg.norm(pts[:, None, :] - pts[None, :, :], axis=-1) + np.eye(len(pts)) * 1e9
+    assert d.min() > 8 - 1e-6
+    ids, p, pairs, valid = build_patch_queries(pts, 32, 32, 160, 160, cfg)
+    o_ids, o_p, o_pairs, o_valid = oscene.build_patch_queries(pts, (0, (32, 32), (160, 160)), AttrDict(cfg))
+    np.testing.assert_array_equal(ids, o_ids)
+    np.testing.assert_array_equal(pairs, o_pairs)
+    np.testing.assert_array_equal(valid, o_valid)
+    assert (pairs[..., 0] == np.arange(len(ids))[:, None]).all()
+    assert (valid[:, :-1] >= valid[:, 1:]).all()                      # valid is a prefix (App. D.5)
+    assert (pairs[..., 1][~valid] == pairs[..., 0][~valid]).all()     # invalid target -> source
+    # empty tile
+    ids, p, pairs, valid = build_patch_queries(pts, 5000, 5000, 5100, 5100, cfg)
+    assert p.shape == (0, 2) and pairs.shape == (0, 16, 2) and valid.shape == (0, 16)
+
+
+def test_sat2graph_format_kats():
+    """The reference's own known-answer tests (graph_utils.py:687-702)."""
+    nodes = np.array([[0.0, 0.0], [1.1, 1.1], [1.6, 1.6]])
+    edges = np.array([[0, 1], [1, 2]])
+    got = convert_to_sat2graph_format(nodes, edges)
+    want = {(0, 0): [(1, 1)], (1, 1): [(0, 0), (2, 2)], (2, 2): [(1, 1)]}
+    assert set(got) == set(want) and all(set(got[k]) == set(want[k]) for k in want)
+    n, e = convert_from_sat2graph_format({(0, 0): [(1, 1)], (1, 1): [(0, 0), (2, 2)], (2, 2): [(1, 1)]})
+    np.testing.assert_array_equal(n, [[0, 0], [1, 1], [2, 2]])
+    np.testing.assert_array_equal(np.array(e), [[0, 1], [1, 0], [1, 2], [2, 1]])
+
+
+def test_shard_tiles_partition():
+    for n, w in [(256, 8), (256, 3), (64, 4), (5, 8), (0, 2)]:
+        spans = [shard_tiles(n, w, r) for r in range(w)]
+        covered = [i for lo, hi in spans for i in range(lo, hi)]
+        assert covered == list(range(n))
+
+
+@pytest.mark.parametrize("version,patch,topo", [("vit_b", 512, "normal"), ("vit_b", 256, "no_transformer"), ("vit_l", 256, "normal")])
+def test_state_dict_layout_matches_appendix_a(version, patch, topo):
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(SAM_VERSION=version, PATCH_SIZE=patch, TOPONET_VERSION=topo, SAM_CKPT_PATH=""))
+    sd = net.state_dict()
+    S = patch // 16
+    D = {"vit_b": 768, "vit_l": 1024}[version]
+    assert tuple(sd["image_encoder.pos_embed"].shape) == (1, S, S, D)
+    assert tuple(sd["image_encoder.patch_embed.proj.weight"].shape) == (D, 3, 16, 16)
+    assert tuple(sd["image_encoder.blocks.0.attn.qkv.weight"].shape) == (3 * D, D)
+    assert tuple(sd["image_encoder.blocks.0.attn.rel_pos_h"].shape) == (27, 64)
+    g = {"vit_b": 2, "vit_l": 5}[version]
+    assert tuple(sd[f"image_encoder.blocks.{g}.attn.rel_pos_w"].shape) == (2 * S - 1, 64)
+    assert tuple(sd["image_encoder.neck.2.weight"].shape) == (256, 256, 3, 3)
+    assert tuple(sd["map_decoder.0.weight"].shape) == (256, 128, 2, 2)
+    assert tuple(sd["map_decoder.7.bias"].shape) == (2,)
+    assert tuple(sd["topo_net.pair_proj.weight"].shape) == (128, 258)
+    assert ("topo_net.transformer_encoder.layers.2.self_attn.in_proj_weight" in sd) == (topo != "no_transformer")
+    assert "pixel_mean" not in sd                                        # non-persistent (model.py:229-230)
+    # same key set / shapes as the oracle (one state dict drives both)
+    from oracle.samroad import AttrDict, SAMRoadOracle
+    o = SAMRoadOracle(AttrDict(SAM_VERSION=version, PATCH_SIZE=patch, TOPONET_VERSION=topo)).state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v.shape) for k, v in o.items()}
+    net.load_state_dict(o, strict=True)
+
+
+def test_lora_keys_and_unsupported_configs():
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, ENCODER_LORA=True, LORA_RANK=4, SAM_CKPT_PATH=""))
+    sd = net.state_dict()
+    assert tuple(sd["image_encoder.blocks.3.attn.qkv.linear_a_q.weight"].shape) == (4, 768)
+    assert tuple(sd["image_encoder.blocks.3.attn.qkv.linear_b_v.weight"].shape) == (768, 4)
+    assert "image_encoder.blocks.3.attn.qkv.weight" in sd
+    with pytest.raises(NotImplementedError):
+        SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, NO_SAM=True))
+    with pytest.raises(NotImplementedError):
+        SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, USE_SAM_DECODER=True))
+    with pytest.raises(AssertionError):
+        SAMRoad(Config(SAM_VERSION="vit_x", PATCH_SIZE=256))
+
+
+def test_no_cpu_fallback():
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, SAM_CKPT_PATH="", ENCODER_DEPTH=1))
+    with pytest.raises(_lib.SrhError):
+        net.infer_masks_and_img_features(torch.zeros(1, 256, 256, 3))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "samroad_hip.h")).read()
+    declared = set(re.findall(r"\b(srh_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.srh_abi_version() == 1
+    # product package must not reference the oracle
+    pkg = os.path.join(ROOT, "sam_road_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

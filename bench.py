@@ -136,9 +136,21 @@ def main():
         n = sum(r["launches"] for r in gemm)
         total_ms = sum(r["ms"] for r in rows)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "srh::gemm_kernel<0> (f16 MFMA GEMM, all linear layers)",
+        # HBM bytes per GEMM launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+        # same command (tools/summarize_profile.py -> profiles/*_hbm_traffic.json); null if no summary is committed
+        traffic, traffic_src = None, None
+        import glob
+        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+        if summaries:
+            try:
+                traffic = json.load(open(summaries[-1]))["_gemm_all"]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(summaries[-1], ROOT)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": "srh::gemm_glds256_kernel / gemm_glds_kernel (f16 MFMA GEMM, all linear layers)",
                            "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
+                           "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(fl / max(n, 1), 1),
                            "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
                            "share_of_gpu_time": round(ms / total_ms, 4) if total_ms else None,
                            "by_class_ms_per_step": {r["name"]: round(r["ms"] / max(1, min(args.steps, 5)), 4) for r in rows}}

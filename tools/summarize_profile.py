@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 outputs merged back under gpurun_out/ into the committed summaries under profiles/.
+
+    python tools/summarize_profile.py r01 gpurun_out/prof_r01 gpurun_out/pmc_fetch_r01 gpurun_out/pmc_write_r01
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary of `bench.py`) and
+profiles/<tag>_hbm_traffic.json: per kernel, mean HBM bytes per launch from the PMC passes
+(FETCH_SIZE and WRITE_SIZE collected in SEPARATE --pmc passes; both are in KiB; on gfx950 FETCH_SIZE
+reports half the bytes of wide coalesced reads, so it is doubled — MI355X_MICROARCH.md §HBM)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def mean_by_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(path, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    tag, prof, fetch, write = sys.argv[1:5]
+    os.makedirs("profiles", exist_ok=True)
+    for f in glob.glob(os.path.join(prof, "*kernel_stats.csv")):
+        shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+    fe, wr = mean_by_kernel(fetch, "FETCH_SIZE"), mean_by_kernel(write, "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fe) | set(wr)):
+        if not k.startswith("srh::"):
+            continue
+        f_kib, n = fe.get(k, (0.0, 0))
+        w_kib, _ = wr.get(k, (0.0, 0))
+        out[k] = {"launches_sampled": n, "fetch_bytes_per_launch": 2 * f_kib * 1024, "write_bytes_per_launch": w_kib * 1024,
+                  "hbm_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024}
+    gem = [v for k, v in out.items() if "gemm" in k]
+    tot_n = sum(v["launches_sampled"] for v in gem)
+    if tot_n:
+        out["_gemm_all"] = {"launches_sampled": tot_n,
+                            "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in gem) / tot_n}
+    json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch (n={v['launches_sampled']})")
+
+
+if __name__ == "__main__":
+    main()

@@ -270,6 +270,7 @@ void gemm_glds_kernel(GemmParams p) {
 // tiles (128 accumulator registers), 2 x 64 KiB LDS stages, one workgroup per CU.  Half the L2->LDS bytes
 // per FLOP of the 128x128 tile and 0.75 ds_read_b128 per MFMA instead of 1.
 // ---------------------------------------------------------------------------------------------------
+template <int ABL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_glds256_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, TILE = BM * BK * 2, STAGE = 2 * TILE;
@@ -320,7 +321,8 @@ void gemm_glds256_kernel(GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
         __syncthreads();
-        if (kt + 1 < nk) SRH_DMA_TILE256(kt + 1, stage ^ 1)
+        if (ABL != 1 && kt + 1 < nk) SRH_DMA_TILE256(kt + 1, stage ^ 1)
+        if (ABL == 2) continue;
         const char* sa = smem + stage * STAGE + x_row0;
         const char* sw = smem + stage * STAGE + TILE + w_row0;
         f16x8 fwA[2], fxA[4], fwB[2], fxB[4];
@@ -346,6 +348,108 @@ void gemm_glds256_kernel(GemmParams p) {
         SRH_MMA4(fwA, fxA)
         SRH_MMA4(fwB, fxB)
         __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+    __builtin_amdgcn_wave_barrier();
+    epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + wm * 128 + 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256x256x32 LDS-DMA RING variant: same 8-wave 4(N)x2(M) decomposition as gemm_glds256_kernel but the k-loop
+// advances 32 deep per step through a 4-stage x 32 KiB LDS ring with the DMA running THREE steps ahead:
+// the barrier that opens step t only needs tile t (s_waitcnt vmcnt(8): the 8 younger DMAs of tiles t+1,
+// t+2 stay in flight across the raw s_barrier), so the ~3k-cycle L2->LDS latency of a 64 KiB/CU burst is
+// covered by three MFMA phases instead of one.  (A __syncthreads() here would drain vmcnt(0) every step.)
+// LDS rows are 64 B (4 chunks of 16 B); chunk index is XOR-ed with (row>>2)&3 — on the DMA source side.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_ring256_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, KS = 32, TILE = BM * KS * 2, STAGE = 2 * TILE, NSTG = 4;   // 16 KiB / 32 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block<4>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nsteps = p.K / KS;
+
+    // DMA piece i (0,1) of a wave covers rows (i*8 + wave)*16 .. +16 of a 256-row operand tile (16 x 64 B = 1 KiB)
+    const int prow = lane >> 2, pc = lane & 3;
+    const char* asrc[2];
+    const char* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 16 + prow;
+        const int c = pc ^ ((r >> 2) & 3);
+        asrc[i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8);
+        wsrc[i] = reinterpret_cast<const char*>(p.W + (size_t)(n0 + r) * p.ldw + c * 8);
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+#define SRH_DMA_RING(t) { const int st_ = (t) & (NSTG - 1); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+        char* d_ = smem + st_ * STAGE + (i * 8 + wave) * 1024; \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)(t) * (KS * 2)), (lds_ptr)d_, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc[i] + (size_t)(t) * (KS * 2)), (lds_ptr)(d_ + TILE), 16, 0, 0); } }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 2) & 3;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 64 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * 64) * 64, x_row0 = (wm * 128) * 64;
+
+    // Software pipeline across steps: the fragments of tile t+1 are read from LDS WHILE the MFMAs of tile t
+    // run (two named fragment sets, loop unrolled by two), so no MFMA ever waits for a ds_read at the top
+    // of a step.  That needs tile t+1 visible at the barrier that opens step t, and frees stage t&3 during
+    // step t already -> the DMA runs FOUR tiles ahead through the four stages.
+    // (nsteps = K/32 is even and >= 4: the launcher requires K % 64 == 0 and K >= 128.)
+#define SRH_WAIT_TILE(x) { const int yg_ = min(2, nsteps - 1 - (x)); \
+        if (yg_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+        else if (yg_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define SRH_RFRAG(F, G, t) { const char* sa_ = smem + ((t) & (NSTG - 1)) * STAGE + x_row0; \
+        const char* sw_ = smem + ((t) & (NSTG - 1)) * STAGE + TILE + w_row0; \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) F[ks][i] = *reinterpret_cast<const f16x8*>(sw_ + foff[ks] + 2048 * i); \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) G[ks][j] = *reinterpret_cast<const f16x8*>(sa_ + foff[ks] + 2048 * j); } }
+#define SRH_RMMA(F, G) { \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(F[ks][i], G[ks][j], acc[i][j]); }
+    f16x8 fwA[2][2], fxA[2][4], fwB[2][2], fxB[2][4];
+    SRH_DMA_RING(0)
+    SRH_DMA_RING(1)
+    SRH_DMA_RING(2)
+    SRH_DMA_RING(3)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // tile 0 landed (12 younger DMAs in flight)
+    __builtin_amdgcn_s_barrier();
+    SRH_RFRAG(fwA, fxA, 0)
+    for (int t = 0; t < nsteps; t += 2) {
+        // ---- even step t: MFMAs on set A (tile t), prefetch set B (tile t+1)
+        SRH_WAIT_TILE(t + 1)
+        __builtin_amdgcn_s_barrier();          // tile t+1 visible to everyone; stage t&3 is free
+        if (t + 4 < nsteps) SRH_DMA_RING(t + 4)
+        SRH_RFRAG(fwB, fxB, t + 1)
+        SRH_RMMA(fwA, fxA)
+        // ---- odd step t+1: MFMAs on set B (tile t+1), prefetch set A (tile t+2)
+        if (t + 2 < nsteps) {
+            SRH_WAIT_TILE(t + 2)
+            __builtin_amdgcn_s_barrier();
+            if (t + 5 < nsteps) SRH_DMA_RING(t + 5)
+            SRH_RFRAG(fwA, fxA, t + 2)
+        }
+        SRH_RMMA(fwB, fxB)
     }
     __syncthreads();
     epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
@@ -487,15 +591,25 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_set = true;
     }
     // 256x256 tiles halve the L2->LDS traffic per FLOP but there are only 256 CUs: use them when the tile
     // count fills the chip evenly (<= one round, or >= 80 % occupancy of the last round), else 128x128.
     const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
     const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
-    if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && fits256) {
-        hipLaunchKernelGGL(gemm_glds256_kernel, dim3(((p.M + 255) / 256) * (p.N / 256)), dim3(512), 131072, stream, p);
+    if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && (fits256 || variant >= 20)) {
+        const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
+        if (variant == 30 && p.K >= 128) {   // experimental ring pipeline: measured no faster than the 2-stage kernel
+            hipLaunchKernelGGL(gemm_ring256_kernel, g256, dim3(512), 131072, stream, p);
+            return hipGetLastError() == hipSuccess ? 0 : -3;
+        }
+        if (variant == 21) hipLaunchKernelGGL(gemm_glds256_kernel<1>, g256, dim3(512), 131072, stream, p);
+        else if (variant == 22) hipLaunchKernelGGL(gemm_glds256_kernel<2>, g256, dim3(512), 131072, stream, p);
+        else hipLaunchKernelGGL(gemm_glds256_kernel<0>, g256, dim3(512), 131072, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);

@@ -47,8 +47,19 @@ struct QState {
     f32x16 o[2];       // O^T accumulators, d tiles 0..31 / 32..63
 };
 
+// K fragments (A operand of S^T) of one key tile: 4 k-steps
+__device__ __forceinline__ void read_kfrag(f16x8 (&kf)[4], const char* k_lds, int lane) {
+    const int half = lane >> 5, row = lane & 31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        kf[ks] = *reinterpret_cast<const f16x8*>(k_lds + row * 128 + swz8(row, ks * 2 + half) * 16);
+}
+
+// One 32-row key tile.  The V^T fragment reads are issued right after the S^T MFMAs and BEFORE the softmax
+// VALU block (order pinned with sched_barrier), so their LDS latency hides behind ~200 VALU instructions
+// instead of stalling the P.V MFMAs — with only 2 waves per SIMD nothing else would cover it.
 template <int WIN>
-__device__ __forceinline__ void attn_tile(QState& st, const char* k_lds, const char* vt_lds,
+__device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], const char* vt_lds,
                                           float rh0, float rh1, float c_exp, int lane) {
     const int half = lane >> 5, row = lane & 31;
     f32x16 s;
@@ -60,10 +71,17 @@ __device__ __forceinline__ void attn_tile(QState& st, const char* k_lds, const c
         s[r] = st.relw[r] + rh;
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const f16x8 a = *reinterpret_cast<const f16x8*>(k_lds + row * 128 + swz8(row, ks * 2 + half) * 16);
-        s = mfma32(a, st.q[ks], s);
-    }
+    for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
+    f16x8 vf[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const int d = dt * 32 + row;
+            const int c = (sx * 2 + half) ^ ((d >> 2) & 3);
+            vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + d * 64 + c * 16);
+        }
+    __builtin_amdgcn_sched_barrier(0);
     if (WIN == 14) {
 #pragma unroll
         for (int r = 12; r < 16; ++r) s[r] = half ? -INFINITY : s[r];   // rows 28..31 are not keys
@@ -73,29 +91,31 @@ __device__ __forceinline__ void attn_tile(QState& st, const char* k_lds, const c
     for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(st.m, mloc);
-    const float alpha = exp2f((st.m - m_new) * c_exp);
-    st.m = m_new;
+    // rescale the running state only when some lane's max moved (wave-uniform branch; after the first
+    // few key tiles the max is usually stable and the 32 accumulator multiplies are skipped)
+    if (__any(m_new != st.m)) {
+        const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c_exp);
+        st.l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+        st.m = m_new;
+    }
+    const float mc = -m_new * c_exp;
     float sum = 0.f;
     f16x8 pb[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f((s[r] - m_new) * c_exp);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c_exp, mc));   // raw v_exp_f32: exp2(-inf) = 0
         sum += pv;
         pb[r >> 3][r & 7] = (f16)pv;
     }
-    st.l = st.l * alpha + sum;
+    st.l += sum;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            const int d = dt * 32 + row;
-            const int c = (sx * 2 + half) ^ ((d >> 2) & 3);
-            const f16x8 a = *reinterpret_cast<const f16x8*>(vt_lds + d * 64 + c * 16);
-            st.o[dt] = mfma32(a, pb[sx], st.o[dt]);
-        }
-    }
+        for (int sx = 0; sx < 2; ++sx) st.o[dt] = mfma32(vf[dt][sx], pb[sx], st.o[dt]);
 }
 
 template <int WIN>
@@ -237,11 +257,18 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
             for (int e = 0; e < 8; ++e) rh[(lane & 31) * 17 + half * 8 + e] = rel[half * 8 + e];
         }
         __builtin_amdgcn_wave_barrier();
+        f16x8 kfA[4], kfB[4];
+        read_kfrag(kfA, k_lds, lane);
 #pragma unroll 1
-        for (int t = 0; t < 7; ++t) {
-            const float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
-            attn_tile<WIN>(st, k_lds + t * 4096, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
+        for (int t = 0; t < 6; t += 2) {     // tiles 0..5 in pairs (next tile's K fragments prefetched), then tile 6
+            float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
+            read_kfrag(kfB, k_lds + (t + 1) * 4096, lane);
+            attn_tile<WIN>(st, kfA, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
+            rh0 = rh[(lane & 31) * 17 + 2 * t + 2]; rh1 = rh[(lane & 31) * 17 + 2 * t + 3];
+            read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
+            attn_tile<WIN>(st, kfB, vt_lds + (t + 1) * 4096, rh0, rh1, c_exp, lane);
         }
+        attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rh[(lane & 31) * 17 + 12], rh[(lane & 31) * 17 + 13], c_exp, lane);
         store_query(st, p, tok, head, lane, valid);
         __builtin_amdgcn_wave_barrier();
     }
@@ -261,10 +288,16 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S, D = p.heads * HD;
     const int nqb = (S * S) / 128;
-    int u = blockIdx.x;
-    const int qb = u % nqb; u /= nqb;
-    const int head = u % p.heads; u /= p.heads;
-    const int b = u;
+    // XCD-aware order (speed only): workgroup u runs on XCD u % 8; give one XCD all nqb query blocks of an
+    // (image, head) back to back so K / V of that head are fetched from HBM once and re-read from its L2.
+    int qb, bh;
+    {
+        const int nbh = p.B * p.heads;
+        const int u = blockIdx.x, xcd = u & 7, j = u >> 3;
+        if ((nbh & 7) == 0) { bh = (j / nqb) * 8 + xcd; qb = j % nqb; }
+        else { bh = u / nqb; qb = u % nqb; }
+    }
+    const int head = bh % p.heads, b = bh / p.heads;
     const size_t tok0 = (size_t)b * S * S;
 
     const int qi = qb * 128 + wave * 32 + (lane & 31);
@@ -279,56 +312,47 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
         for (int e = 0; e < WP / 2; ++e) rh[(lane & 31) * (WP + 1) + half * (WP / 2) + e] = rel[half * (WP / 2) + e];
     }
 
-    // staging registers: 2 K chunks per thread, one V^T block for threads < 128
-    uint4 rk[2], rv[4];
-    auto load_stage = [&](int sidx) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int it = tid + 256 * e;            // (tile-in-stage, row i, chunk c)
-            const int c = it & 7, i = (it >> 3) & 31, t = sidx * 2 + (it >> 8);
-            const size_t ktok = tok0 + (size_t)t * 32 + i;
-            rk[e] = *reinterpret_cast<const uint4*>(p.qkv + ktok * p.ld + D + head * HD + c * 8);
-        }
-        if (tid < 128) {
-            const int dc = tid & 7, kq = (tid >> 3) & 7, t = sidx * 2 + (tid >> 6);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const size_t ktok = tok0 + (size_t)t * 32 + kq * 4 + e;
-                rv[e] = *reinterpret_cast<const uint4*>(p.qkv + ktok * p.ld + 2 * D + head * HD + dc * 8);
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-        char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int it = tid + 256 * e;
-            const int c = it & 7, i = (it >> 3) & 31, tl = it >> 8;
-            *reinterpret_cast<uint4*>(base + tl * 4096 + i * 128 + swz8(i, c) * 16) = rk[e];
-        }
-        if (tid < 128) {
-            const int dc = tid & 7, kq = (tid >> 3) & 7, tl = tid >> 6;
-            vt_write(base + 8192 + tl * 4096, kq, dc, rv[0], rv[1], rv[2], rv[3]);
-        }
-    };
+    // staging registers (named, not arrays: hipcc keeps lambda-captured staging arrays in scratch):
+    // 2 K chunks per thread, one 4-key x 8-dim V block for threads < 128
+    uint4 rk0, rk1, rv0, rv1, rv2, rv3;
+    const int s_c = tid & 7, s_i = (tid >> 3) & 31;                 // K item: chunk, row (tile = e)
+    const int s_dc = tid & 7, s_kq = (tid >> 3) & 7, s_tl = tid >> 6;  // V item (tid < 128)
+    const f16* kbase = p.qkv + (tok0 + s_i) * p.ld + D + head * HD + s_c * 8;
+    const f16* vbase = p.qkv + (tok0 + s_kq * 4) * p.ld + 2 * D + head * HD + s_dc * 8;
+#define SRH_LOAD_STAGE(sidx) { \
+        rk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)((sidx) * 2 + 0) * 32 * p.ld); \
+        rk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)((sidx) * 2 + 1) * 32 * p.ld); \
+        if (tid < 128) { const f16* vb_ = vbase + (size_t)((sidx) * 2 + s_tl) * 32 * p.ld; \
+            rv0 = *reinterpret_cast<const uint4*>(vb_); rv1 = *reinterpret_cast<const uint4*>(vb_ + p.ld); \
+            rv2 = *reinterpret_cast<const uint4*>(vb_ + 2 * p.ld); rv3 = *reinterpret_cast<const uint4*>(vb_ + 3 * p.ld); } }
+#define SRH_STORE_STAGE(buf) { char* base_ = smem + (buf) * STAGE; \
+        *reinterpret_cast<uint4*>(base_ + s_i * 128 + swz8(s_i, s_c) * 16) = rk0; \
+        *reinterpret_cast<uint4*>(base_ + 4096 + s_i * 128 + swz8(s_i, s_c) * 16) = rk1; \
+        if (tid < 128) vt_write(base_ + 8192 + s_tl * 4096, s_kq, s_dc, rv0, rv1, rv2, rv3); }
 
     const float c_exp = p.scale * 1.4426950408889634f;
     constexpr int NSTAGE = NT / 2;
-    load_stage(0);
-    store_stage(0);
+    SRH_LOAD_STAGE(0)
+    SRH_STORE_STAGE(0)
     __syncthreads();
     for (int sidx = 0; sidx < NSTAGE; ++sidx) {
         const int buf = sidx & 1;
-        if (sidx + 1 < NSTAGE) load_stage(sidx + 1);
+        const int snext = sidx + 1 < NSTAGE ? sidx + 1 : sidx;   // last stage re-loads itself (no branch)
+        SRH_LOAD_STAGE(snext)
         const char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-            const int t = sidx * 2 + tl;
-            const float rh0 = rh[(lane & 31) * (WP + 1) + t * RPT];
-            const float rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + t * RPT + 1] : 0.f;
-            attn_tile<WIN>(st, base + tl * 4096, base + 8192 + tl * 4096, rh0, rh1, c_exp, lane);
+        {
+            f16x8 kfA[4], kfB[4];
+            read_kfrag(kfA, base, lane);
+            read_kfrag(kfB, base + 4096, lane);
+            const int t0 = sidx * 2;
+            float rh0 = rh[(lane & 31) * (WP + 1) + t0 * RPT];
+            float rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + t0 * RPT + 1] : 0.f;
+            attn_tile<WIN>(st, kfA, base + 8192, rh0, rh1, c_exp, lane);
+            rh0 = rh[(lane & 31) * (WP + 1) + (t0 + 1) * RPT];
+            rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + (t0 + 1) * RPT + 1] : 0.f;
+            attn_tile<WIN>(st, kfB, base + 8192 + 4096, rh0, rh1, c_exp, lane);
         }
-        if (sidx + 1 < NSTAGE) store_stage(buf ^ 1);
+        SRH_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
     store_query(st, p, tok, head, lane, true);

@@ -8,75 +8,107 @@
 
 namespace srh {
 
-template <int EPL, int VW>  // elements per lane, vector width (floats)
+// R rows per wave per iteration (all R rows' loads are issued before any is consumed: the kernel is
+// latency-bound otherwise — PMC showed >90 % of wave cycles parked in s_waitcnt with one row in flight),
+// grid-stride over row groups.
+template <int EPL, int VW, int R>  // elements per lane, vector width (floats), rows per wave per iteration
 __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
     constexpr int NV = EPL / VW;
-    const float* x = p.x + (size_t)row * p.D;
-    float v[EPL];
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int off = (c * 64 + lane) * VW;
-        if (VW == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(x + off);
-            v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
-        } else {
-            const float2 t = *reinterpret_cast<const float2*>(x + off);
-            v[c * 2 + 0] = t.x; v[c * 2 + 1] = t.y;
-        }
-    }
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    // per-lane affine parameters are row-invariant: load once
+    float g[EPL], be[EPL];
     if (p.gamma) {
-        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) s += v[e];
-        const float mean = wave_sum(s) / (float)p.D;
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-        const float rstd = rsqrtf(wave_sum(q) / (float)p.D + p.eps);
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
+        for (int c = 0; c < NV; ++c) {   // vector loads: 24 scalar dword loads per row made the kernel VMEM-issue bound
             const int off = (c * 64 + lane) * VW;
-#pragma unroll
-            for (int e = 0; e < VW; ++e) {
-                float y = v[c * VW + e] * rstd * p.gamma[off + e] + p.beta[off + e];
-                if (p.act == 1) y = gelu_erf(y);
-                v[c * VW + e] = y;
+            if (VW == 4) {
+                const float4 tg = *reinterpret_cast<const float4*>(p.gamma + off), tb = *reinterpret_cast<const float4*>(p.beta + off);
+                g[c * 4] = tg.x; g[c * 4 + 1] = tg.y; g[c * 4 + 2] = tg.z; g[c * 4 + 3] = tg.w;
+                be[c * 4] = tb.x; be[c * 4 + 1] = tb.y; be[c * 4 + 2] = tb.z; be[c * 4 + 3] = tb.w;
+            } else {
+                const float2 tg = *reinterpret_cast<const float2*>(p.gamma + off), tb = *reinterpret_cast<const float2*>(p.beta + off);
+                g[c * 2] = tg.x; g[c * 2 + 1] = tg.y; be[c * 2] = tb.x; be[c * 2 + 1] = tb.y;
             }
         }
     }
+    for (int row0 = wave_global * R; row0 < p.M; row0 += n_waves * R) {
+        float v[R][EPL];
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int off = (c * 64 + lane) * VW;
-        if (p.out_f16) {
-            f16* o = p.out_f16 + (size_t)row * p.D + off;
-            if (VW == 4) {
-                f16x4 h = {(f16)v[c * 4], (f16)v[c * 4 + 1], (f16)v[c * 4 + 2], (f16)v[c * 4 + 3]};
-                *reinterpret_cast<f16x4*>(o) = h;
-            } else {
-                f16x2 h = {(f16)v[c * 2], (f16)v[c * 2 + 1]};
-                *reinterpret_cast<f16x2*>(o) = h;
+        for (int r = 0; r < R; ++r) {
+            const int row = min(row0 + r, p.M - 1);
+            const float* x = p.x + (size_t)row * p.D;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int off = (c * 64 + lane) * VW;
+                if (VW == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + off);
+                    v[r][c * 4 + 0] = t.x; v[r][c * 4 + 1] = t.y; v[r][c * 4 + 2] = t.z; v[r][c * 4 + 3] = t.w;
+                } else {
+                    const float2 t = *reinterpret_cast<const float2*>(x + off);
+                    v[r][c * 2 + 0] = t.x; v[r][c * 2 + 1] = t.y;
+                }
             }
         }
-        if (p.out_f32) {
-            float* o = p.out_f32 + (size_t)row * p.D + off;
-            if (VW == 4) *reinterpret_cast<float4*>(o) = make_float4(v[c * 4], v[c * 4 + 1], v[c * 4 + 2], v[c * 4 + 3]);
-            else *reinterpret_cast<float2*>(o) = make_float2(v[c * 2], v[c * 2 + 1]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (p.gamma) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) s += v[r][e];
+                const float mean = wave_sum(s) / (float)p.D;
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { v[r][e] -= mean; q += v[r][e] * v[r][e]; }
+                const float rstd = rsqrtf(wave_sum(q) / (float)p.D + p.eps);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    float y = v[r][e] * rstd * g[e] + be[e];
+                    if (p.act == 1) y = gelu_erf(y);
+                    v[r][e] = y;
+                }
+            }
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int off = (c * 64 + lane) * VW;
+                if (p.out_f16) {
+                    f16* o = p.out_f16 + (size_t)row * p.D + off;
+                    if (VW == 4) {
+                        f16x4 h = {(f16)v[r][c * 4], (f16)v[r][c * 4 + 1], (f16)v[r][c * 4 + 2], (f16)v[r][c * 4 + 3]};
+                        *reinterpret_cast<f16x4*>(o) = h;
+                    } else {
+                        f16x2 h = {(f16)v[r][c * 2], (f16)v[r][c * 2 + 1]};
+                        *reinterpret_cast<f16x2*>(o) = h;
+                    }
+                }
+                if (p.out_f32) {
+                    float* o = p.out_f32 + (size_t)row * p.D + off;
+                    if (VW == 4) *reinterpret_cast<float4*>(o) = make_float4(v[r][c * 4], v[r][c * 4 + 1], v[r][c * 4 + 2], v[r][c * 4 + 3]);
+                    else *reinterpret_cast<float2*>(o) = make_float2(v[r][c * 2], v[r][c * 2 + 1]);
+                }
+            }
         }
     }
 }
 
+template <int EPL, int VW, int R>
+static void launch_ln(const NormParams& p, hipStream_t s) {
+    const int groups = (p.M + R - 1) / R;                 // wave-iterations needed
+    const int blocks = min((groups + 3) / 4, 256 * 8);    // <= 8 blocks per CU, grid-stride beyond
+    hipLaunchKernelGGL((layernorm_kernel<EPL, VW, R>), dim3(blocks), dim3(256), 0, s, p);
+}
+
 int launch_layernorm(const NormParams& p, hipStream_t s) {
     if (p.M <= 0) return 0;
-    const dim3 grid((p.M + 3) / 4), block(256);
     switch (p.D) {
-        case 128:  hipLaunchKernelGGL((layernorm_kernel<2, 2>), grid, block, 0, s, p); break;
-        case 256:  hipLaunchKernelGGL((layernorm_kernel<4, 4>), grid, block, 0, s, p); break;
-        case 768:  hipLaunchKernelGGL((layernorm_kernel<12, 4>), grid, block, 0, s, p); break;
-        case 1024: hipLaunchKernelGGL((layernorm_kernel<16, 4>), grid, block, 0, s, p); break;
-        case 1280: hipLaunchKernelGGL((layernorm_kernel<20, 4>), grid, block, 0, s, p); break;
+        case 128:  launch_ln<2, 2, 4>(p, s); break;
+        case 256:  launch_ln<4, 4, 4>(p, s); break;
+        case 768:  launch_ln<12, 4, 2>(p, s); break;
+        case 1024: launch_ln<16, 4, 2>(p, s); break;
+        case 1280: launch_ln<20, 4, 2>(p, s); break;
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -66,3 +66,21 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def calib():
+    """Calibrate achievable HBM bandwidth with torch's own streaming kernels."""
+    x = torch.randn(16384, 768, device="cuda")
+    big = torch.randn(64 * 1024 * 1024, device="cuda")   # 256 MB
+    ms = timeit(lambda: x.half())
+    print(f"torch f32->f16 16384x768: {ms*1e3:7.1f} us  {16384*768*6/ms/1e6:8.1f} GB/s")
+    ms = timeit(lambda: big.clone())
+    print(f"torch clone 256MB: {ms*1e3:7.1f} us  {big.numel()*8/ms/1e6:8.1f} GB/s")
+    ms = timeit(lambda: x.clone())
+    print(f"torch clone 50MB: {ms*1e3:7.1f} us  {x.numel()*8/ms/1e6:8.1f} GB/s")
+    ms = timeit(lambda: torch.nn.functional.layer_norm(x, (768,)))
+    print(f"torch layer_norm f32 16384x768: {ms*1e3:7.1f} us  {x.numel()*8/ms/1e6:8.1f} GB/s")
+
+
+if "calib" in sys.argv:
+    calib()

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -37,7 +38,7 @@ struct srh_ctx {
     int device = 0;
     std::string err;
     // encoder / decoder workspace
-    DevBuf a0, x, xn16, qkv16, rel, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16, d2_16;
+    DevBuf a0, x, xn16, delta16, qkv16, rel, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16, d2_16;
     DevBuf scores_ws, emb_ws, counter;
     // toponet workspace
     DevBuf t_feat16, t_pf16, t_pair16, t_x, t_x16, t_qkv16, t_at16, t_y, t_h16;
@@ -362,6 +363,7 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
     rc |= c->a0.ensure(T * 768 * 2);
     rc |= c->x.ensure(T * D * 4);
     rc |= c->xn16.ensure(T * D * 2);
+    rc |= c->delta16.ensure(T * D * 2);
     rc |= c->qkv16.ensure(T * 3 * D * 2);
     rc |= c->rel.ensure(T * w->heads * 64 * 4);
     rc |= c->attn16.ensure(T * D * 2);
@@ -394,11 +396,28 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         g.bias = w->patch_b; g.pos = w->pos; g.pos_rows = S * S; g.out_f32 = c->x.as<float>(); g.ldc = D;
         TRY(gemm(c, "gemm_patch_embed", g, s));
     }
+    // Residual stream: x stays fp32.  Where the persistent q192 GEMM applies (gemm_q192.hip: fp16 output only), proj / fc2
+    // write their branch output (bias included) as fp16 into delta16 and the NEXT LayerNorm pass folds "x += delta" into
+    // its read of x — the same HBM bytes as the GEMM-epilogue residual add, but moved out of the GEMM's exposed epilogue
+    // into a streaming kernel.  Otherwise the GEMM epilogue adds the residual itself.
+    static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
+    bool pending = false;                                 // delta16 holds a branch output not yet added to x
+    auto branch_gemm = [&](const char* cls, const f16* A, int lda, const f16* W, int K, const float* bias) -> int {
+        GemmParams gq;
+        gq.A = A; gq.lda = lda; gq.W = W; gq.ldw = K; gq.M = T; gq.N = D; gq.K = K; gq.bias = bias;
+        gq.out_f16 = c->delta16.as<f16>(); gq.ldc16 = D;
+        if (use_q192 && q192_preferred(gq)) { pending = true; return gemm(c, cls, gq, s); }
+        GemmParams gp = gq;
+        gp.out_f16 = nullptr; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
+        return gemm(c, cls, gp, s);
+    };
     for (const BlockW& b : w->blocks) {
         NormParams ln;
         ln.x = c->x.as<float>(); ln.M = T; ln.D = D; ln.eps = 1e-6f; ln.out_f16 = c->xn16.as<f16>();
         ln.gamma = b.ln1_g; ln.beta = b.ln1_b;
-        TRYK(c, "layernorm", 0, (double)T * D * 6, s, launch_layernorm(ln, s));
+        ln.delta16 = pending ? c->delta16.as<f16>() : nullptr; ln.x_out = c->x.as<float>();
+        TRYK(c, "layernorm", 0, (double)T * D * (pending ? 12 : 6), s, launch_layernorm(ln, s));
+        pending = false;
         GemmParams g;
         g.A = c->xn16.as<f16>(); g.lda = D; g.W = b.qkv_w; g.ldw = D; g.M = T; g.N = 3 * D; g.K = D;
         g.bias = b.qkv_b; g.out_f16 = c->qkv16.as<f16>(); g.ldc16 = 3 * D;
@@ -413,26 +432,23 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         ap.out = c->attn16.as<f16>(); ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = b.win;
         ap.scale = 1.0f / sqrtf((float)hd);
         TRYK(c, b.win == S ? "attn_global" : "attn_window", attn_flops(B, S, heads, hd, b.win), 0, s, launch_attention(ap, s));
-        GemmParams gp;
-        gp.A = c->attn16.as<f16>(); gp.lda = D; gp.W = b.proj_w; gp.ldw = D; gp.M = T; gp.N = D; gp.K = D;
-        gp.bias = b.proj_b; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
-        TRY(gemm(c, "gemm_proj", gp, s));
+        TRY(branch_gemm("gemm_proj", c->attn16.as<f16>(), D, b.proj_w, D, b.proj_b));
         ln.gamma = b.ln2_g; ln.beta = b.ln2_b;
-        TRYK(c, "layernorm", 0, (double)T * D * 6, s, launch_layernorm(ln, s));
+        ln.delta16 = pending ? c->delta16.as<f16>() : nullptr;
+        TRYK(c, "layernorm", 0, (double)T * D * (pending ? 12 : 6), s, launch_layernorm(ln, s));
+        pending = false;
         GemmParams g1;
         g1.A = c->xn16.as<f16>(); g1.lda = D; g1.W = b.fc1_w; g1.ldw = D; g1.M = T; g1.N = 4 * D; g1.K = D;
         g1.bias = b.fc1_b; g1.act = 1; g1.out_f16 = c->hid16.as<f16>(); g1.ldc16 = 4 * D;
         TRY(gemm(c, "gemm_fc1", g1, s));
-        GemmParams g2;
-        g2.A = c->hid16.as<f16>(); g2.lda = 4 * D; g2.W = b.fc2_w; g2.ldw = 4 * D; g2.M = T; g2.N = D; g2.K = 4 * D;
-        g2.bias = b.fc2_b; g2.resid = c->x.as<float>(); g2.ldr = D; g2.out_f32 = c->x.as<float>(); g2.ldc = D;
-        TRY(gemm(c, "gemm_fc2", g2, s));
+        TRY(branch_gemm("gemm_fc2", c->hid16.as<f16>(), 4 * D, b.fc2_w, 4 * D, b.fc2_b));
     }
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d  (channels-last: LN2d is a row LN)
     {
         NormParams cast;
         cast.x = c->x.as<float>(); cast.M = T; cast.D = D; cast.out_f16 = c->xn16.as<f16>();
-        TRYK(c, "layernorm", 0, (double)T * D * 6, s, launch_layernorm(cast, s));
+        cast.delta16 = pending ? c->delta16.as<f16>() : nullptr;     // the last fc2 branch output, if still pending
+        TRYK(c, "layernorm", 0, (double)T * D * (pending ? 8 : 6), s, launch_layernorm(cast, s));
         GemmParams g;
         g.A = c->xn16.as<f16>(); g.lda = D; g.W = w->neck0_w; g.ldw = D; g.M = T; g.N = 256; g.K = D;
         g.out_f32 = c->n1.as<float>(); g.ldc = 256;

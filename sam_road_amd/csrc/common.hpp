@@ -34,6 +34,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// exact-erf GELU without erff:  gelu(x) = max(x,0) - |x| * Phi(-|x|)  with  Phi(-a) = 2^(-r(a)),  r a degree-5
+// polynomial fitted (tools/fit_gelu.py) so that |a*2^-r(a) - a*Phi(-a)| <= 1.6e-6 for every a >= 0 — three
+// orders of magnitude below the fp16 rounding of the stored activation.  5 FMA + 1 v_exp_f32 + 2 VALU per
+// element (A&S 7.1.26 erf needed ~16 VALU + rcp + exp: it made the fc1 epilogue VALU-bound).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float a = fabsf(x);
+    float r = 0.00048291164585022967f;
+    r = fmaf(r, a, -0.0071898452371611365f);
+    r = fmaf(r, a, 0.05218537922649359f);
+    r = fmaf(r, a, 0.4595148493607732f);
+    r = fmaf(r, a, 1.1510354141727006f);
+    r = fmaf(r, a, 1.0f);
+    const float e = __builtin_amdgcn_exp2f(-r);
+    return fmaf(-a, e, fmaxf(x, 0.f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -20,17 +20,6 @@ namespace srh {
 
 constexpr int BK = 64;
 
-// fast exact-GELU: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 rounding
-// of the stored activation); ~15 VALU ops per element instead of erff's ~40.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    const float erf_v = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erf_v);
-}
-
 // Source row for the activation operand.  AMODE 0: plain row m.  AMODE 1: implicit 3x3 conv over
 // an [B,S,S,C] channels-last grid (zero padding 1): k-tile kt addresses tap = (kt*BK)/C.
 template <int AMODE>
@@ -119,37 +108,45 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&ac
             }
     }
     __builtin_amdgcn_wave_barrier();
-    const int c = lane & 15, rsub = lane >> 4;
-    const int n = nw + c * 4;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4*>(p.bias + n);
+    // read-back: 8 lanes own one 64-column row segment (2 chunks = 8 columns each), 8 rows per pass
+    const int c2 = (lane & 7) * 2, rsub = lane >> 3;
+    const int n = nw + c2 * 4;
+    float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
+    if (p.bias) { bias0 = *reinterpret_cast<const float4*>(p.bias + n); bias1 = *reinterpret_cast<const float4*>(p.bias + n + 4); }
 #pragma unroll 4
-    for (int pass = 0; pass < 16; ++pass) {
-        const int r = pass * 4 + rsub;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int r = pass * 8 + rsub;
         const int m = mw + r;
-        const f32x4 t = *reinterpret_cast<const f32x4*>(wbuf + r * 256 + ((c ^ (r & 15)) << 4));
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(wbuf + r * 256 + ((c2 ^ (r & 15)) << 4));
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(wbuf + r * 256 + (((c2 + 1) ^ (r & 15)) << 4));
         if (m >= p.M) continue;
-        float v[4] = {t[0] + bias.x, t[1] + bias.y, t[2] + bias.z, t[3] + bias.w};
+        float v[8] = {t0[0] + bias0.x, t0[1] + bias0.y, t0[2] + bias0.z, t0[3] + bias0.w,
+                      t1[0] + bias1.x, t1[1] + bias1.y, t1[2] + bias1.z, t1[3] + bias1.w};
         if (p.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
         } else if (p.act == 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.pos) {
-            const float4 b = *reinterpret_cast<const float4*>(p.pos + (size_t)(m % p.pos_rows) * p.N + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            const float* pp = p.pos + (size_t)(m % p.pos_rows) * p.N + n;
+            const float4 b0 = *reinterpret_cast<const float4*>(pp), b1 = *reinterpret_cast<const float4*>(pp + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
         if (p.resid) {
-            const float4 b = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            const float* pr = p.resid + (size_t)m * p.ldr + n;
+            const float4 b0 = *reinterpret_cast<const float4*>(pr), b1 = *reinterpret_cast<const float4*>(pr + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
-        if (p.out_f32)
-            *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.out_f32) {
+            float* po = p.out_f32 + (size_t)m * p.ldc + n;
+            *reinterpret_cast<float4*>(po) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(po + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
         if (p.out_f16) {
-            f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h;
+            f16x8 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3], (f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+            *reinterpret_cast<f16x8*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h;
         }
     }
 }
@@ -457,6 +454,165 @@ void gemm_ring256_kernel(GemmParams p) {
     epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 256x256x64 PING-PONG variant (the default for the big layers).  Same 8-wave decomposition and epilogue as
+// gemm_glds256_kernel (wave tile 64(N) x 128(M) = 2x4 MFMA tiles) but the k-tile is processed as FOUR
+// quadrant phases and the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run ONE PHASE
+// SEGMENT APART: while a group issues its 8 MFMAs of a quadrant the other group issues its fragment
+// ds_reads and its share of the LDS-DMA, so the matrix pipe of every SIMD always has a wave in an MFMA
+// segment.  Each operand k-tile lives in LDS as two 16 KiB half-tiles (W0/W1: the waves' first/second
+// 32 weight rows, X0/X1: the waves' first/second 64 activation rows); a quadrant phase consumes one
+// half-tile for good, which is re-staged (k-tile t+2) one or two phases later, ONE half-tile per phase:
+//     P1: read W0,X0 | DMA X1(t+1) | mma(W0,X0)      P2: read W1 | DMA W0(t+2) | mma(W1,X0)
+//     P3: read X1    | DMA X0(t+2) | mma(W1,X1)      P4:  -      | DMA W1(t+2) | mma(W0,X1)
+// The DMA queue is never drained inside the loop: one counted s_waitcnt vmcnt(6) per k-tile (in P4) retires
+// k-tile t+1 while three half-tiles of k-tile t+2 stay in flight across the raw s_barriers.
+// Hazards (MI355X guide §5 "8-phase template"): RAW - a half-tile is read >= 1 phase after the counted wait +
+// barrier that retired it; WAR - re-staged two phases after its last ds_read, or one phase after when an
+// lgkmcnt before the reading phase's barrier retired the reads (W0: lgkmcnt(8) in P1).
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+template <int ABL>   // ablation aid: 0 normal, 1 no DMA in the loop, 2 no MFMA, 3 no epilogue
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_pp256_kernel(GemmParams p) {
+    constexpr int HALF = 128 * 128, BUF = 4 * HALF;       // 16 KiB half-tile, 64 KiB k-tile (W0,X0,W1,X1)
+    constexpr int SW0 = 0, SX0 = HALF, SW1 = 2 * HALF, SX1 = 3 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wq = wave & 3;               // group (= M half of the tile), N quarter
+    int tile_m, tile_n;
+    tile_of_block<4>((p.M + 255) / 256, p.N / 256, tile_m, tile_n);
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int nk = p.K / BK;
+
+    // DMA: a wave moves pieces {wave, wave+8} (8 rows x 128 B each) of every half-tile.  Half-tile local row
+    // lr -> tile row:  W_h: (lr>>5)*64 + h*32 + (lr&31)     X_h: (lr>>6)*128 + h*64 + (lr&63)
+    const int prow = lane >> 3, pc = lane & 7;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    int vW[2][2], vX[2][2];                                // [half][piece] byte offsets of this lane's 16 B
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (wave + 8 * i) * 8 + prow;
+        const int c = pc ^ ((lr >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int nr = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            const int mr = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);
+            vW[h][i] = nr * p.ldw * 2 + c * 16;
+            vX[h][i] = mr * p.lda * 2 + c * 16;
+        }
+    }
+#define SRH_PP_DMA(rs, vo, kt, buf, slot) { \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(smem + (buf) * BUF + (slot) + wave * 1024), 16, vo[0], (kt) * (BK * 2), 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(smem + (buf) * BUF + (slot) + (wave + 8) * 1024), 16, vo[1], (kt) * (BK * 2), 0, 0); }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int wbase = wq * 4096, xbase = g * 8192;
+
+    // prologue: all of k-tile 0, three half-tiles of k-tile 1 (X1(1) is issued by P1 of k-tile 0)
+    SRH_PP_DMA(rsW, vW[0], 0, 0, SW0) SRH_PP_DMA(rsX, vX[0], 0, 0, SX0)
+    SRH_PP_DMA(rsW, vW[1], 0, 0, SW1) SRH_PP_DMA(rsX, vX[1], 0, 0, SX1)
+    if (nk > 1) {
+        SRH_PP_DMA(rsW, vW[0], 1, 1, SW0) SRH_PP_DMA(rsX, vX[0], 1, 1, SX0) SRH_PP_DMA(rsW, vW[1], 1, 1, SW1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();              // stagger: group 1 runs one segment behind group 0
+
+    f16x8 fw0[4], fw1[4], fx[2][4];
+#define SRH_PP_RDW(F, buf, slot) { const char* s_ = smem + (buf) * BUF + (slot) + wbase; \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) F[ks] = *reinterpret_cast<const f16x8*>(s_ + foff[ks]); }
+#define SRH_PP_RDX(buf, slot) { const char* s_ = smem + (buf) * BUF + (slot) + xbase; \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { fx[0][ks] = *reinterpret_cast<const f16x8*>(s_ + foff[ks]); \
+                                                        fx[1][ks] = *reinterpret_cast<const f16x8*>(s_ + foff[ks] + 4096); } }
+// The MFMA builtins are pure register operations: neither sched_barrier nor the asm memory clobbers keep the
+// instruction selector from sliding them across the segment barriers.  Pin them through their operands: the
+// fragments become opaque right after the lgkmcnt wait (no MFMA above it) and the accumulators right before
+// the closing barrier (no MFMA below it).
+#define SRH_PP_PIN4(F) { _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(F[ks])); }
+#define SRH_PP_MMA(F, i, j0) { if (ABL != 2) { \
+    SRH_PP_PIN4(F) SRH_PP_PIN4(fx[0]) SRH_PP_PIN4(fx[1]) \
+    __builtin_amdgcn_s_setprio(1); \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { acc[i][j0] = mfma32(F[ks], fx[0][ks], acc[i][j0]); \
+                                                        acc[i][j0 + 1] = mfma32(F[ks], fx[1][ks], acc[i][j0 + 1]); } \
+    asm volatile("" : "+v"(acc[i][j0])); asm volatile("" : "+v"(acc[i][j0 + 1])); \
+    __builtin_amdgcn_s_setprio(0); } else { \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(F[ks]), "v"(fx[0][ks]), "v"(fx[1][ks])); } }
+#define SRH_PP_SEG_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+    for (int t = 0; t < nk; ++t) {
+        const int b = t & 1;
+        const bool dma1 = ABL != 1 && t + 1 < nk, dma2 = ABL != 1 && t + 2 < nk;
+        // ---- P1: quadrant (W0, X0)
+        SRH_PP_RDW(fw0, b, SW0)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_PP_RDX(b, SX0)
+        if (dma1) SRH_PP_DMA(rsX, vX[1], t + 1, b ^ 1, SX1)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 4 W0 reads have returned: W0 may be re-staged in P2
+        SRH_PP_SEG_BARRIER()
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_PP_MMA(fw0, 0, 0)
+        SRH_PP_SEG_BARRIER()
+        // ---- P2: quadrant (W1, X0)
+        SRH_PP_RDW(fw1, b, SW1)
+        if (dma2) SRH_PP_DMA(rsW, vW[0], t + 2, b, SW0)
+        SRH_PP_SEG_BARRIER()
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_PP_MMA(fw1, 1, 0)
+        SRH_PP_SEG_BARRIER()
+        // ---- P3: quadrant (W1, X1)
+        SRH_PP_RDX(b, SX1)
+        if (dma2) SRH_PP_DMA(rsX, vX[0], t + 2, b, SX0)
+        SRH_PP_SEG_BARRIER()
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_PP_MMA(fw1, 1, 2)
+        SRH_PP_SEG_BARRIER()
+        // ---- P4: quadrant (W0, X1); retire k-tile t+1
+        if (dma2) {
+            SRH_PP_DMA(rsW, vW[1], t + 2, b, SW1)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        SRH_PP_SEG_BARRIER()
+        SRH_PP_MMA(fw0, 0, 2)
+        SRH_PP_SEG_BARRIER()
+    }
+    if (g == 0) __builtin_amdgcn_s_barrier();              // re-align the groups
+    __syncthreads();
+    if (ABL == 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+    epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + g * 128, n0 + wq * 64, lane);
+    __builtin_amdgcn_wave_barrier();
+    epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + g * 128 + 64, n0 + wq * 64, lane);
+}
+
 // Tile configuration: WN x WM waves, each wave TN x TM MFMA tiles of 32x32 (N = weight rows, M = activation rows)
 //   small: 2x2 waves, 2x2 tiles -> 128x128, 256 threads, 64 KiB LDS, 2 workgroups / CU
 //   big:   4x2 waves, 2x4 tiles -> 256(N) x 256(M), 512 threads, 128 KiB LDS, 1 workgroup / CU
@@ -582,6 +738,10 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.conv_S > 0) return launch_cfg<1, 2, 2, 2, 2>(p, stream);
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;   // tuning aid
     const int variant = p.variant ? p.variant : env_variant;
+    if (variant >= 50 && variant <= 52) return launch_gemm_q192(p, stream, variant - 50);
+    // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
+    static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
+    if (variant == 0 && use_q192 && q192_preferred(p)) return launch_gemm_q192(p, stream, 0);
     if (variant == 1) return launch_cfg<0, 2, 2, 2, 2>(p, stream);
     if (variant == 2 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<0, 4, 2, 2, 4>(p, stream);
     if (false) return (p.N % 256 == 0) ? launch_cfg<0, 4, 2, 2, 4>(p, stream) : -2;
@@ -592,6 +752,10 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -605,6 +769,13 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
         if (variant == 30 && p.K >= 128) {   // experimental ring pipeline: measured no faster than the 2-stage kernel
             hipLaunchKernelGGL(gemm_ring256_kernel, g256, dim3(512), 131072, stream, p);
+            return hipGetLastError() == hipSuccess ? 0 : -3;
+        }
+        if (variant >= 40 && variant <= 43) {
+            if (variant == 40) hipLaunchKernelGGL(gemm_pp256_kernel<0>, g256, dim3(512), 131072, stream, p);
+            if (variant == 41) hipLaunchKernelGGL(gemm_pp256_kernel<1>, g256, dim3(512), 131072, stream, p);
+            if (variant == 42) hipLaunchKernelGGL(gemm_pp256_kernel<2>, g256, dim3(512), 131072, stream, p);
+            if (variant == 43) hipLaunchKernelGGL(gemm_pp256_kernel<3>, g256, dim3(512), 131072, stream, p);
             return hipGetLastError() == hipSuccess ? 0 : -3;
         }
         if (variant == 21) hipLaunchKernelGGL(gemm_glds256_kernel<1>, g256, dim3(512), 131072, stream, p);

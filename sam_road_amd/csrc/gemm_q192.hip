@@ -1,0 +1,338 @@
+// Persistent 256(M) x 192(N) x 64 f16 MFMA GEMM with a DEFERRED, register-held epilogue:
+//     OUT16[M,N] = act(A[M,K] * W[N,K]^T + bias)          (fp16 out, fp32 accumulate)
+// for the four big linear layers of every SAM ViT block (qkv, proj, fc1, fc2 — SURVEY.md §2.1 K4/K7/K8).
+//
+// Why this kernel exists (measured on MI355X, profiles/r01_gemm_ablation.md): with K = 768 the k-loop of a
+// 256x256 tile lasts ~20 us while its epilogue — 128..256 KiB through ONE CU's store path at ~10 B/clk — lasts
+// 7..13 us, during which the matrix pipes idle; the epilogue, not the k-loop, was half of the GEMM time.
+// Here one workgroup per CU walks several output tiles.  When a tile's k-loop ends, each wave only CONVERTS its
+// accumulators to packed fp16 (48 VGPRs) and starts the next tile's k-loop at once (the operand DMA ring never
+// drains across tiles); the packed tile is finished (bias, GELU) and stored in 24 small steps hidden in the
+// ds_read/DMA segments of the next tile's first 12 k-tiles, beside the partner group's MFMA segments.
+// 192-wide tiles also make every ViT-B layer an exact number of rounds over 256 CUs at B = 16
+// (768 / 256 / 1024 / 256 tiles), which 256x256 tiles do not (576 / 192 / 768 / 192).
+//
+// Structure: 8 waves = 2 groups (M halves) x 4 N quarters; wave tile 48(N) x 128(M) = 3 x 8 tiles of
+// v_mfma_f32_16x16x32_f16 issued "transposed" (A operand = weight rows) so a lane owns 4 consecutive output
+// columns.  The two groups (the two waves of every SIMD) run one segment apart: while one issues the 24 MFMAs of
+// a phase the other issues its fragment ds_reads, its LDS-DMA pieces and its epilogue step.  Per k-tile:
+//     P0: read W, X0 | DMA X1(s+1)         | mma(W, X0)        P1: read X1 | DMA W, X0(s+2) | mma(W, X1)
+// Every phase finishes its ds_reads (lgkmcnt(0)) BEFORE its first barrier, so a half-tile may be re-staged one
+// phase after it was read; each DMA is issued two phases before the counted s_waitcnt vmcnt(7) that retires it
+// and three phases before it is read (RAW: read >= 1 phase after wait + barrier, one barrier more because the
+// groups are staggered).  LDS: 2 x (W 24 KiB | X0 16 KiB | X1 16 KiB) + 3 bias slots = 136 KiB.
+// Epilogue stores share vmcnt with the DMA loads and may retire out of order with them: every counted wait uses
+// N = the number of younger LOADS only (safe for any store completion order), and each store is issued right
+// after a wait so that it has a full phase to be acknowledged before the next one.
+#include <type_traits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace srh {
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+// LDS map: W(buf0) W(buf1) | X0(buf0) X1(buf0) X0(buf1) X1(buf1) | bias.  Both W slabs sit within 64 KiB of the W
+// fragment base and all four X slabs within 64 KiB of the X fragment base, so every fragment ds_read is one of
+// FOUR address registers plus an immediate offset.
+constexpr int Q_WBUF = 24576, Q_XBASE = 2 * Q_WBUF, Q_XBUF = 32768, Q_X0 = 0, Q_X1 = 16384;
+constexpr int Q_BIAS = Q_XBASE + 2 * Q_XBUF;      // 114688; 3 slots x 8 waves x 1 KiB
+constexpr int Q_LDS = Q_BIAS + 3 * 8192;          // 139264 B
+
+// virtual block vb (runs on XCD vb % 8; speed only) -> tile origin: every XCD owns a contiguous run of the tile
+// order, tiles ordered in groups of 4 tile rows with the column index outer (shared A / W panels stay in its L2)
+__device__ __forceinline__ void q_tile_of(int vb, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0) {
+    const int xcd = vb & 7, loc = vb >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int group = t / (4 * tiles_n), within = t - group * 4 * tiles_n;
+    const int first_m = group * 4, gsz = min(4, tiles_m - first_m);
+    m0 = (first_m + within % gsz) * 256;
+    n0 = (within / gsz) * 192;
+}
+
+// Counted wait: n = number of VMEM operations (DMA loads AND epilogue stores) issued after the one that must
+// have landed.  gfx9-family vmcnt retires loads and stores in issue order (the compiler's own counted waits rely
+// on it), so younger stores are simply counted; a smaller n is always safe.
+__device__ __forceinline__ void q_wait_vm(int n) {      // wave-uniform n
+    switch (n) {
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int ABL, int ACT, bool BIAS>   // ABL ablation aid: 0 normal, 1 no epilogue stores, 2 no MFMA; ACT 0 none / 1 GELU / 2 ReLU
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_q192_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, nq = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nk = p.K / 64;
+    const int tiles_m = p.M / 256, tiles_n = p.N / 192, ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int S_total = my_tiles * nk;
+
+    // ---- LDS-DMA lane constants.  A wave moves pieces {wave, wave+8, (wave+16)} (8 rows x 128 B) of each slab;
+    // the 16-byte chunk XOR swizzle the fragment reads need is applied to the per-lane SOURCE address.
+    const int prow = lane >> 3, pc = lane & 7;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out_f16, 0, 0x7fffffff, 0x00020000);
+    int vW[3], vX[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int lr = (wave + 8 * i) * 8 + prow;                 // W slab row = tile column 0..191
+        vW[i] = lr * p.ldw * 2 + ((pc ^ ((lr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (wave + 8 * i) * 8 + prow;                 // X_h slab row: group (lr>>6), row (lr&63) of its half h
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            vX[h][i] = ((lr >> 6) * 128 + h * 64 + (lr & 63)) * p.lda * 2 + ((pc ^ ((lr >> 1) & 7)) << 4);
+    }
+    const int vB = min(lane, 47) * 16;                            // 192 bias floats = 48 lanes x 16 B
+    // Epilogue lane layout.  The MFMA leaves lane (l4, l15) with row l15, columns 4*l4..+3 of a 16x16 tile: ADJACENT lanes
+    // hold DIFFERENT rows, so a direct store is 64 separate 8-byte writes per instruction (store-issue bound: measured
+    // ~100 clk per instruction).  When a tile is packed, each lane pulls (ds_bpermute) the pair that makes lane L own
+    // row L>>2, columns 4*(L&3)..+3: four adjacent lanes then write one contiguous 32-byte sector.
+    const int erow = lane >> 2, ecol = (lane & 3) * 4;
+    const int epull = ((lane & 3) * 16 + (lane >> 2)) * 4;        // ds_bpermute byte address of the source lane
+    const int vO = ((g * 128 + erow) * p.ldc16 + nq * 48 + ecol) * 2;
+    const int ldsB = Q_BIAS + wave * 1024 + (nq * 48 + ecol) * 4;
+
+    // ---- tile bookkeeping (wave-uniform).  c_*: tile being computed; n_*: the tile after it (the DMA streams cross
+    // into it one / two k-tiles early).  Stream A: W, X0 (+ the tile's bias at its first k-tile); stream B: X1.
+    int c_m0, c_n0, c_slot = 0, n_m0 = 0, n_n0 = 0;
+    q_tile_of(blockIdx.x, ntiles, tiles_m, tiles_n, c_m0, c_n0);
+    if (my_tiles > 1) q_tile_of(blockIdx.x + G, ntiles, tiles_m, tiles_n, n_m0, n_n0);
+    int a_kt = 0, a_m0 = c_m0, a_n0 = c_n0, a_slot = 0;
+    int b_kt = 0, b_m0 = c_m0;
+    int p_slot = 0, p_soff = 0;                                   // finished tile: bias slot, byte offset of its origin in OUT16
+    const int ld16 = p.ldc16 * 32;                                // bytes per 16 output rows
+
+#define Q_ISSUE_A(buf) { \
+    if (BIAS && a_kt == 0) \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vptr)(smem + Q_BIAS + a_slot * 8192 + wave * 1024), 16, vB, a_n0 * 4, 0, 0); \
+    const int sw_ = a_n0 * p.ldw * 2 + a_kt * 128, sx_ = a_m0 * p.lda * 2 + a_kt * 128; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_vptr)(smem + (buf) * Q_WBUF + (wave + 8 * i_) * 1024), 16, vW[i_], sw_, 0, 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(smem + Q_XBASE + (buf) * Q_XBUF + Q_X0 + (wave + 8 * i_) * 1024), 16, vX[0][i_], sx_, 0, 0); \
+    if (++a_kt == nk) { a_kt = 0; a_m0 = n_m0; a_n0 = n_n0; a_slot = a_slot == 2 ? 0 : a_slot + 1; } }
+#define Q_ISSUE_B(buf) { \
+    const int sx_ = b_m0 * p.lda * 2 + b_kt * 128; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(smem + Q_XBASE + (buf) * Q_XBUF + Q_X1 + (wave + 8 * i_) * 1024), 16, vX[1][i_], sx_, 0, 0); \
+    if (++b_kt == nk) { b_kt = 0; b_m0 = n_m0; } }
+
+    f32x4 acc[3][8];
+    f16x4 o[3][8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][j] = f16x4{0, 0, 0, 0}; }
+
+    // fragment addressing: 16x16x32 operand, lane (row l15, 16-byte chunk ks*4 + l4 of the 128-byte k-row), swizzled
+    const int fkey = (l15 >> 1) & 7;
+    const int fch0 = ((0 + l4) ^ fkey) << 4, fch1 = ((4 + l4) ^ fkey) << 4;
+    const char* const wad0 = smem + (nq * 48 + l15) * 128 + fch0;
+    const char* const wad1 = smem + (nq * 48 + l15) * 128 + fch1;
+    const char* const xad0 = smem + Q_XBASE + (g * 64 + l15) * 128 + fch0;
+    const char* const xad1 = smem + Q_XBASE + (g * 64 + l15) * 128 + fch1;
+
+    // ---- prologue: k-tiles 0 and 1 of the first tile (X1(1) is issued by P0 of step 0)
+    Q_ISSUE_A(0)
+    Q_ISSUE_B(0)
+    Q_ISSUE_A(1)
+    q_wait_vm(7);
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();                     // stagger: group 1 runs one segment behind group 0
+
+    f16x8 wf[3][2], xf[4][2];
+#define Q_RDW(b) { \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) { wf[nt][0] = *reinterpret_cast<const f16x8*>(wad0 + (b) * Q_WBUF + nt * 2048); \
+                                                        wf[nt][1] = *reinterpret_cast<const f16x8*>(wad1 + (b) * Q_WBUF + nt * 2048); } }
+#define Q_RDX(b, off) { \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { xf[mt][0] = *reinterpret_cast<const f16x8*>(xad0 + (b) * Q_XBUF + (off) + mt * 2048); \
+                                                        xf[mt][1] = *reinterpret_cast<const f16x8*>(xad1 + (b) * Q_XBUF + (off) + mt * 2048); } }
+    // MFMA builtins are pure register ops: pin them between the segment barriers through their operands
+#define Q_MMA(h, EPI) { \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) { asm volatile("" : "+v"(wf[nt][0])); asm volatile("" : "+v"(wf[nt][1])); } \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(xf[mt][0])); asm volatile("" : "+v"(xf[mt][1])); } \
+    if (ABL != 2) { \
+    __builtin_amdgcn_s_setprio(1); \
+    EPI \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[nt][(h) * 4 + mt] = mfma16(wf[nt][ks], xf[mt][ks], acc[nt][(h) * 4 + mt]); \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][(h) * 4 + mt])); \
+    asm volatile("" : "+v"(rpend)); \
+    __builtin_amdgcn_s_setprio(0); } }
+#define Q_SEG_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    // deferred epilogue step I (0..23) of the finished tile: accumulator tile (nt = I % 3, j = I / 3)
+#define Q_EPI_BIAS(I, dst) { if (BIAS) dst = *reinterpret_cast<const f32x4*>( \
+        (const char*)__builtin_assume_aligned(smem + ldsB + p_slot * 8192 + ((I) % 3) * 64, 16)); }
+    // compute half (VALU only; issued INSIDE the MFMA segment, between the matrix instructions) ...
+#define Q_EPI_COMPUTE(I, bias4, r) { \
+    f16x4 h_ = o[(I) % 3][(I) / 3]; \
+    asm volatile("" : "+v"(h_));            /* opaque here: keeps hipcc from hoisting all 24 unpacks to the block top (spills) */ \
+    float v_[4] = {(float)h_[0] + bias4[0], (float)h_[1] + bias4[1], (float)h_[2] + bias4[2], (float)h_[3] + bias4[3]}; \
+    if (ACT == 1) { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) v_[e_] = gelu_fast(v_[e_]); } \
+    else if (ACT == 2) { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) v_[e_] = fmaxf(v_[e_], 0.f); } \
+    const f16x4 r_ = {(f16)v_[0], (f16)v_[1], (f16)v_[2], (f16)v_[3]}; \
+    r = __builtin_bit_cast(v2i, r_); }
+    // ... and store half (issued in the NEXT ds_read/DMA segment, right after its counted wait)
+#define Q_EPI_STORE(I, r) { \
+    int sb_ = p_soff; \
+    asm volatile("" : "+s"(sb_)); \
+    if (ABL != 1) __builtin_amdgcn_raw_buffer_store_b64(r, rsO, vO, sb_ + ((I) / 3) * ld16 + ((I) % 3) * 32, 0); }
+
+    int s_left = S_total;                        // k-tile steps of this workgroup not yet started
+    bool have_prev = false, pend = false;        // pend: rpend holds a finished epilogue step that still has to be stored
+    v2i rpend = {0, 0};
+    // One block = 12 k-tiles = 24 phases, fully unrolled.  tr: the deferred epilogue of the previous tile rides along, one
+    // step per phase.  Its bias read and VALU math are issued UNCONDITIONALLY (straight-line code the scheduler can weave
+    // between the MFMAs; garbage when tr is false) — only the store is predicated.
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        for (int kb = 0; kb < nk; kb += 12) {
+            const bool tr = have_prev && kb == 0;
+            const bool lastblk = kb + 12 == nk;
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk, --s_left) {
+                const int b = kk & 1;            // == global step parity (nk and kb are even)
+                const bool more1 = s_left > 1, more2 = s_left > 2;
+                // ================= P0: W x X0          (epilogue step I = 2 kk: bias read here, math inside the MFMA
+                f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};   //  segment, store in the next ds_read segment)
+                Q_EPI_BIAS(2 * kk, bias4)
+                Q_RDW(b)
+                Q_RDX(b, Q_X0)
+                if (more1) Q_ISSUE_B(b ^ 1)
+                __builtin_amdgcn_sched_barrier(0);
+                // X1(s) has landed; younger: A(s+1) 5 (+ bias), X1(s+1) 2, and the epilogue stores of the last two segments
+                if (!more1) q_wait_vm(0);
+                else {
+                    const int nst = kk >= 2 ? 2 : kk;
+                    if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
+                    else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
+                }
+                if (kk == 0) { if (pend) Q_EPI_STORE(23, rpend) pend = false; }
+                else if (tr) Q_EPI_STORE(2 * kk - 1, rpend)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Q_SEG_BARRIER()
+                Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend))
+                Q_SEG_BARRIER()
+                // ================= P1: W x X1
+                Q_EPI_BIAS(2 * kk + 1, bias4)
+                Q_RDX(b, Q_X1)
+                if (more2) Q_ISSUE_A(b)
+                __builtin_amdgcn_sched_barrier(0);
+                // W, X0(s+1) landed; younger: X1(s+1) 2, A(s+2) 5 (+ bias), and the epilogue stores of the last two segments
+                if (!more2) { if (!more1) q_wait_vm(0); else if (tr) q_wait_vm(4); else q_wait_vm(2); }
+                else {
+                    const int nst = kk >= 1 ? 2 : 0;
+                    if (BIAS && kk == 10 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
+                    else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
+                }
+                if (tr) Q_EPI_STORE(2 * kk, rpend)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Q_SEG_BARRIER()
+                Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend))
+                Q_SEG_BARRIER()
+            }
+            pend = tr;
+        }
+        // tile done: flush the last deferred step of the tile before (its origin offset is about to be replaced), then
+        // hand the accumulators to the deferred epilogue (fp16, pre-bias, store lane layout) and go on
+        if (pend) { Q_EPI_STORE(23, rpend) pend = false; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f16x4 h = {(f16)acc[i][j][0], (f16)acc[i][j][1], (f16)acc[i][j][2], (f16)acc[i][j][3]};
+                const v2i hv = __builtin_bit_cast(v2i, h);
+                const v2i pv = {__builtin_amdgcn_ds_bpermute(epull, hv[0]), __builtin_amdgcn_ds_bpermute(epull, hv[1])};
+                o[i][j] = __builtin_bit_cast(f16x4, pv);
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        have_prev = true;
+        p_soff = (c_m0 * p.ldc16 + c_n0) * 2; p_slot = c_slot;
+        c_slot = c_slot == 2 ? 0 : c_slot + 1;
+        c_m0 = n_m0; c_n0 = n_n0;
+        if (ti + 2 < my_tiles) q_tile_of(blockIdx.x + (ti + 2) * G, ntiles, tiles_m, tiles_n, n_m0, n_n0);
+    }
+    if (g == 0) __builtin_amdgcn_s_barrier();                     // re-align the groups
+    // last tile: nothing left to hide the epilogue behind
+#pragma unroll
+    for (int I = 0; I < 24; ++I) {
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        v2i r;
+        Q_EPI_BIAS(I, bias4)
+        Q_EPI_COMPUTE(I, bias4, r)
+        Q_EPI_STORE(I, r)
+    }
+}
+
+bool q192_preferred(const GemmParams& p) {   // enough tiles to occupy the chip
+    return q192_supported(p) && (p.M / 256) * (p.N / 192) >= 128;
+}
+
+bool q192_supported(const GemmParams& p) {
+    return p.conv_S == 0 && p.out_f16 && !p.out_f32 && !p.resid && !p.pos && p.M >= 256 && p.M % 256 == 0 &&
+           p.N % 192 == 0 && p.K % 768 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.ldc16 % 4 == 0 &&
+           (size_t)p.M * p.lda * 2 < 0x7fffffffull && (size_t)p.N * p.ldw * 2 < 0x7fffffffull &&
+           (size_t)p.M * p.ldc16 * 2 < 0x7fffffffull;
+}
+
+template <int ACT, bool BIAS>
+static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int ablation) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<1, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<2, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        attr_set = true;
+    }
+    if (ablation == 1) hipLaunchKernelGGL((gemm_q192_kernel<1, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else if (ablation == 2) hipLaunchKernelGGL((gemm_q192_kernel<2, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
+}
+
+int launch_gemm_q192(const GemmParams& p, hipStream_t stream, int ablation) {
+    if (!q192_supported(p)) return -2;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
+        n_cu = prop.multiProcessorCount;
+    }
+    const int ntiles = (p.M / 256) * (p.N / 192);
+    const int grid = ntiles < n_cu ? ntiles : (n_cu / 8) * 8;    // persistent: one workgroup per CU
+    if (p.bias) {
+        if (p.act == 1) q192_launch<1, true>(p, stream, grid, ablation);
+        else if (p.act == 2) q192_launch<2, true>(p, stream, grid, ablation);
+        else q192_launch<0, true>(p, stream, grid, ablation);
+    } else {
+        if (p.act == 1) q192_launch<1, false>(p, stream, grid, ablation);
+        else if (p.act == 2) q192_launch<2, false>(p, stream, grid, ablation);
+        else q192_launch<0, false>(p, stream, grid, ablation);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace srh

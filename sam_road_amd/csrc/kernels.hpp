@@ -18,6 +18,10 @@ struct GemmParams {
     int variant = 0;                           // 0 LDS-DMA 128x128 (default), 1 register-staged 128x128, 2 register-staged 256x256
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
+// persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip); fp16 output, no residual / pos-embed
+bool q192_supported(const GemmParams& p);
+bool q192_preferred(const GemmParams& p);
+int launch_gemm_q192(const GemmParams& p, hipStream_t s, int ablation = 0);
 
 // Row LayerNorm (biased variance) f32 [M,D] -> fp16 and/or f32; gamma == nullptr => cast only.
 struct NormParams {
@@ -25,6 +29,9 @@ struct NormParams {
     const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-6f;
     int act = 0;                               // 1: GELU after affine
     f16* out_f16 = nullptr; float* out_f32 = nullptr;
+    // optional fused residual add: x' = x + delta16 (fp16 [M,D], a GEMM's deferred-epilogue output) is what gets
+    // normalised, and is written back to x_out (may alias x) when x_out != nullptr
+    const f16* delta16 = nullptr; float* x_out = nullptr;
 };
 int launch_layernorm(const NormParams& p, hipStream_t s);
 

@@ -35,10 +35,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     }
     for (int row0 = wave_global * R; row0 < p.M; row0 += n_waves * R) {
         float v[R][EPL];
+        f16 dl[R][EPL];                                   // optional fp16 residual-branch output to fold in (dead when unused)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = min(row0 + r, p.M - 1);
             const float* x = p.x + (size_t)row * p.D;
+            if (p.delta16) {
+                const f16* d = p.delta16 + (size_t)row * p.D;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const int off = (c * 64 + lane) * VW;
+                    if (VW == 4) {
+                        const f16x4 t = *reinterpret_cast<const f16x4*>(d + off);
+                        dl[r][c * 4 + 0] = t[0]; dl[r][c * 4 + 1] = t[1]; dl[r][c * 4 + 2] = t[2]; dl[r][c * 4 + 3] = t[3];
+                    } else {
+                        const f16x2 t = *reinterpret_cast<const f16x2*>(d + off);
+                        dl[r][c * 2 + 0] = t[0]; dl[r][c * 2 + 1] = t[1];
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
                 const int off = (c * 64 + lane) * VW;
@@ -54,6 +69,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
+            if (p.delta16) {                              // x <- x + delta (the residual add the GEMM epilogue no longer does)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[r][e] += (float)dl[r][e];
+                if (p.x_out && row < p.M) {
+                    float* xo = p.x_out + (size_t)row * p.D;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        const int off = (c * 64 + lane) * VW;
+                        if (VW == 4) *reinterpret_cast<float4*>(xo + off) = make_float4(v[r][c * 4], v[r][c * 4 + 1], v[r][c * 4 + 2], v[r][c * 4 + 3]);
+                        else *reinterpret_cast<float2*>(xo + off) = make_float2(v[r][c * 2], v[r][c * 2 + 1]);
+                    }
+                }
+            }
             if (p.gamma) {
                 float s = 0.f;
 #pragma unroll

@@ -1,0 +1,113 @@
+// GEMM variant probe: times srh::launch_gemm variants on the ViT-B layer shapes (interleaved rounds, random data)
+// and checks each against a naive one-thread-per-output kernel.
+//   tools/probes/build_probes.sh
+//   tools/probes/gemm_probe [rounds] [variants: e.g. 0,40,41,42,43] [shapes: qkv,proj,fc1,fc2]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "../../sam_road_amd/csrc/kernels.hpp"
+using namespace srh;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+__global__ void naive_gemm(const f16* A, const f16* W, const float* bias, const float* resid, int M, int N, int K, int act,
+                           float* out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[(size_t)m * K + k] * (float)W[(size_t)n * K + k];
+    s += bias[n];
+    if (act == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));
+    if (resid) s += resid[(size_t)m * N + n];
+    out[(size_t)m * N + n] = s;
+}
+__global__ void diff_kernel(const float* ref, const float* o32, const f16* o16, size_t n, float* maxabs, float* maxref) {
+    float d = 0.f, r = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = o32 ? o32[i] : (float)o16[i];
+        const float e = fabsf(v - ref[i]);
+        d = fmaxf(d, (e == e) ? e : 1e30f);
+        r = fmaxf(r, fabsf(ref[i]));
+    }
+    atomicMax((int*)maxabs, __float_as_int(d));
+    atomicMax((int*)maxref, __float_as_int(r));
+}
+
+struct Shape { const char* name; int M, N, K, act; bool resid, f16out; };
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 7;
+    std::vector<int> variants;
+    { std::string v = argc > 2 ? argv[2] : "0,40"; size_t p = 0; while (p < v.size()) { size_t q = v.find(',', p); if (q == std::string::npos) q = v.size(); variants.push_back(atoi(v.substr(p, q - p).c_str())); p = q + 1; } }
+    const std::string which = argc > 3 ? argv[3] : "qkv,proj,fc1,fc2";
+    const int T = argc > 4 ? atoi(argv[4]) : 16384;
+    const int D = 768;
+    const Shape all[] = {{"qkv", T, 3 * D, D, 0, false, true}, {"proj", T, D, D, 0, true, false},
+                         {"fc1", T, 4 * D, D, 1, false, true}, {"fc2", T, D, 4 * D, 0, true, false},
+                         {"hproj", T, D, D, 0, false, true}, {"hfc2", T, D, 4 * D, 0, false, true}};
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (const Shape& s : all) {
+        if (("," + which + ",").find(std::string(",") + s.name + ",") == std::string::npos) continue;
+        const size_t nA = (size_t)s.M * s.K, nW = (size_t)s.N * s.K, nO = (size_t)s.M * s.N;
+        std::vector<f16> hA(nA), hW(nW);
+        std::vector<float> hb(s.N), hR(s.resid ? nO : 0);
+        for (auto& v : hA) v = (f16)(0.5f * nd(rng));
+        for (auto& v : hW) v = (f16)(0.05f * nd(rng));
+        for (auto& v : hb) v = 0.1f * nd(rng);
+        for (auto& v : hR) v = nd(rng);
+        f16 *dA, *dW, *o16; float *db, *dR = nullptr, *o32, *ref, *dmax;
+        CK(hipMalloc(&dA, nA * 2)); CK(hipMalloc(&dW, nW * 2)); CK(hipMalloc(&db, s.N * 4));
+        CK(hipMalloc(&o16, nO * 2)); CK(hipMalloc(&o32, nO * 4)); CK(hipMalloc(&ref, nO * 4)); CK(hipMalloc(&dmax, 8));
+        if (s.resid) { CK(hipMalloc(&dR, nO * 4)); CK(hipMemcpy(dR, hR.data(), nO * 4, hipMemcpyHostToDevice)); }
+        CK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), s.N * 4, hipMemcpyHostToDevice));
+        naive_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(dA, dW, db, dR, s.M, s.N, s.K, s.act, ref);
+        CK(hipDeviceSynchronize());
+        auto make = [&](int variant) {
+            GemmParams g;
+            g.A = dA; g.lda = s.K; g.W = dW; g.ldw = s.K; g.M = s.M; g.N = s.N; g.K = s.K; g.bias = db;
+            g.resid = dR; g.ldr = s.N; g.act = s.act; g.variant = variant;
+            if (s.f16out) { g.out_f16 = o16; g.ldc16 = s.N; } else { g.out_f32 = o32; g.ldc = s.N; }
+            return g;
+        };
+        std::vector<std::vector<float>> times(variants.size());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (size_t vi = 0; vi < variants.size(); ++vi) {      // correctness + warm-up
+            CK(hipMemset(o16, 0xff, nO * 2)); CK(hipMemset(o32, 0xff, nO * 4)); CK(hipMemset(dmax, 0, 8));
+            const GemmParams g = make(variants[vi]);
+            const int rc = launch_gemm(g, 0);
+            CK(hipDeviceSynchronize());
+            diff_kernel<<<1024, 256>>>(ref, s.f16out ? nullptr : o32, s.f16out ? o16 : nullptr, nO, dmax, dmax + 1);
+            float h[2]; CK(hipMemcpy(h, dmax, 8, hipMemcpyDeviceToHost));
+            printf("  check %-5s variant %3d rc=%d  max|diff|=%.3e  (max|ref|=%.2f)\n", s.name, variants[vi], rc, h[0], h[1]);
+        }
+        for (int r = 0; r < rounds; ++r)
+            for (size_t vi = 0; vi < variants.size(); ++vi) {
+                const GemmParams g = make(variants[vi]);
+                launch_gemm(g, 0);
+                CK(hipEventRecord(e0, 0));
+                for (int it = 0; it < 10; ++it) launch_gemm(g, 0);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                times[vi].push_back(ms / 10);
+            }
+        for (size_t vi = 0; vi < variants.size(); ++vi) {
+            std::sort(times[vi].begin(), times[vi].end());
+            const float med = times[vi][times[vi].size() / 2], mn = times[vi][0];
+            const double fl = 2.0 * s.M * (double)s.N * s.K;
+            printf("%-5s M=%d N=%d K=%d variant %3d: median %8.1f us (%7.1f TFLOP/s)   min %8.1f us (%7.1f)\n", s.name, s.M, s.N, s.K,
+                   variants[vi], med * 1e3, fl / med / 1e9, mn * 1e3, fl / mn / 1e9);
+        }
+        for (void* q : {(void*)dA, (void*)dW, (void*)db, (void*)o16, (void*)o32, (void*)ref, (void*)dmax, (void*)dR}) if (q) (void)hipFree(q);
+    }
+    return 0;
+}

@@ -201,6 +201,11 @@ void gemm_q192_kernel(GemmParams p) {
     asm volatile("" : "+s"(sb_)); \
     if (ABL != 1) __builtin_amdgcn_raw_buffer_store_b64(r, rsO, vO, sb_ + ((I) / 3) * ld16 + ((I) % 3) * 32, 0); }
 
+    // ABL == 3: waves 0 and 4 of workgroup 0 accumulate s_memtime deltas per segment part (dbg[wave>>2][phase][part])
+    unsigned long long tsum[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}, tprev = 0;
+#define Q_TICK(ph, part) { if (ABL == 3) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        tsum[ph][part] += t_ - tprev; tprev = t_; } }
+    if (ABL == 3) tprev = __builtin_amdgcn_s_memtime();
     int s_left = S_total;                        // k-tile steps of this workgroup not yet started
     bool have_prev = false, pend = false;        // pend: rpend holds a finished epilogue step that still has to be stored
     v2i rpend = {0, 0};
@@ -220,40 +225,54 @@ void gemm_q192_kernel(GemmParams p) {
                 Q_EPI_BIAS(2 * kk, bias4)
                 Q_RDW(b)
                 Q_RDX(b, Q_X0)
+                // the deferred-epilogue store goes FIRST: behind this segment's LDS-DMA pieces it would sit in the VMEM queue
+                // until the TA has worked them off (measured: ~400 clk behind five pieces)
+                if (kk == 0) { if (pend) Q_EPI_STORE(23, rpend) pend = false; }
+                else if (tr) Q_EPI_STORE(2 * kk - 1, rpend)
                 if (more1) Q_ISSUE_B(b ^ 1)
                 __builtin_amdgcn_sched_barrier(0);
-                // X1(s) has landed; younger: A(s+1) 5 (+ bias), X1(s+1) 2, and the epilogue stores of the last two segments
+                Q_TICK(0, 0)
+                // X1(s) has landed; younger: A(s+1) 5 (+ bias), X1(s+1) 2, and the epilogue stores of this and the last segment
                 if (!more1) q_wait_vm(0);
                 else {
-                    const int nst = kk >= 2 ? 2 : kk;
+                    const int nst = kk >= 1 ? 2 : 0;
                     if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
                     else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
                 }
-                if (kk == 0) { if (pend) Q_EPI_STORE(23, rpend) pend = false; }
-                else if (tr) Q_EPI_STORE(2 * kk - 1, rpend)
+                Q_TICK(0, 1)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Q_TICK(0, 2)
                 Q_SEG_BARRIER()
+                Q_TICK(0, 3)
                 Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend))
+                Q_TICK(0, 4)
                 Q_SEG_BARRIER()
+                Q_TICK(0, 5)
                 // ================= P1: W x X1
                 Q_EPI_BIAS(2 * kk + 1, bias4)
                 Q_RDX(b, Q_X1)
+                if (tr) Q_EPI_STORE(2 * kk, rpend)
                 if (more2) Q_ISSUE_A(b)
                 __builtin_amdgcn_sched_barrier(0);
-                // W, X0(s+1) landed; younger: X1(s+1) 2, A(s+2) 5 (+ bias), and the epilogue stores of the last two segments
+                Q_TICK(1, 0)
+                // W, X0(s+1) landed; younger: X1(s+1) 2, A(s+2) 5 (+ bias), and the epilogue stores of this and the last segment
                 if (!more2) { if (!more1) q_wait_vm(0); else if (tr) q_wait_vm(4); else q_wait_vm(2); }
                 else {
-                    const int nst = kk >= 1 ? 2 : 0;
+                    const int nst = kk >= 1 ? 2 : 1;
                     if (BIAS && kk == 10 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
                     else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
                 }
-                if (tr) Q_EPI_STORE(2 * kk, rpend)
+                Q_TICK(1, 1)
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Q_TICK(1, 2)
                 Q_SEG_BARRIER()
+                Q_TICK(1, 3)
                 Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend))
+                Q_TICK(1, 4)
                 Q_SEG_BARRIER()
+                Q_TICK(1, 5)
             }
             pend = tr;
         }
@@ -277,6 +296,13 @@ void gemm_q192_kernel(GemmParams p) {
         if (ti + 2 < my_tiles) q_tile_of(blockIdx.x + (ti + 2) * G, ntiles, tiles_m, tiles_n, n_m0, n_n0);
     }
     if (g == 0) __builtin_amdgcn_s_barrier();                     // re-align the groups
+    if (ABL == 3 && p.dbg && blockIdx.x == 0 && nq == 0 && lane == 0) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int part = 0; part < 6; ++part) p.dbg[(g * 2 + ph) * 6 + part] = tsum[ph][part];
+        p.dbg[24] = (unsigned long long)S_total;
+    }
     // last tile: nothing left to hide the epilogue behind
 #pragma unroll
     for (int I = 0; I < 24; ++I) {
@@ -306,10 +332,12 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<1, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<2, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         attr_set = true;
     }
     if (ablation == 1) hipLaunchKernelGGL((gemm_q192_kernel<1, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else if (ablation == 2) hipLaunchKernelGGL((gemm_q192_kernel<2, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else if (ablation == 3) hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS>), dim3(grid), dim3(512), Q_LDS, stream, p);
 }
 

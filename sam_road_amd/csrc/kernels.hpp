@@ -15,6 +15,7 @@ struct GemmParams {
     f16* out_f16 = nullptr; int ldc16 = 0;
     int act = 0;                               // 0 none, 1 exact-erf GELU, 2 ReLU (applied after bias)
     int conv_S = 0, conv_C = 0;                // >0: implicit 3x3 conv over [B,S,S,C]
+    unsigned long long* dbg = nullptr;         // tuning aid (gemm_q192 ablation 3): per-segment cycle sums
     int variant = 0;                           // 0 LDS-DMA 128x128 (default), 1 register-staged 128x128, 2 register-staged 256x256
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);

@@ -62,7 +62,8 @@ int main(int argc, char** argv) {
         for (auto& v : hW) v = (f16)(0.05f * nd(rng));
         for (auto& v : hb) v = 0.1f * nd(rng);
         for (auto& v : hR) v = nd(rng);
-        f16 *dA, *dW, *o16; float *db, *dR = nullptr, *o32, *ref, *dmax;
+        f16 *dA, *dW, *o16; float *db, *dR = nullptr, *o32, *ref, *dmax; unsigned long long* ddbg;
+        CK(hipMalloc(&ddbg, 64 * 8)); CK(hipMemset(ddbg, 0, 64 * 8));
         CK(hipMalloc(&dA, nA * 2)); CK(hipMalloc(&dW, nW * 2)); CK(hipMalloc(&db, s.N * 4));
         CK(hipMalloc(&o16, nO * 2)); CK(hipMalloc(&o32, nO * 4)); CK(hipMalloc(&ref, nO * 4)); CK(hipMalloc(&dmax, 8));
         if (s.resid) { CK(hipMalloc(&dR, nO * 4)); CK(hipMemcpy(dR, hR.data(), nO * 4, hipMemcpyHostToDevice)); }
@@ -76,6 +77,7 @@ int main(int argc, char** argv) {
             g.A = dA; g.lda = s.K; g.W = dW; g.ldw = s.K; g.M = s.M; g.N = s.N; g.K = s.K; g.bias = db;
             g.resid = dR; g.ldr = s.N; g.act = s.act; g.variant = variant;
             if (s.f16out) { g.out_f16 = o16; g.ldc16 = s.N; } else { g.out_f32 = o32; g.ldc = s.N; }
+            g.dbg = ddbg;
             return g;
         };
         std::vector<std::vector<float>> times(variants.size());
@@ -88,6 +90,16 @@ int main(int argc, char** argv) {
             diff_kernel<<<1024, 256>>>(ref, s.f16out ? nullptr : o32, s.f16out ? o16 : nullptr, nO, dmax, dmax + 1);
             float h[2]; CK(hipMemcpy(h, dmax, 8, hipMemcpyDeviceToHost));
             printf("  check %-5s variant %3d rc=%d  max|diff|=%.3e  (max|ref|=%.2f)\n", s.name, variants[vi], rc, h[0], h[1]);
+            if (variants[vi] == 53) {
+                unsigned long long hd[32]; CK(hipMemcpy(hd, ddbg, 25 * 8, hipMemcpyDeviceToHost));
+                const double n = (double)hd[24];
+                const char* part[6] = {"issue(reads+dma)", "vmcnt wait", "store+lgkm wait", "barrier1", "mfma seg", "barrier2"};
+                for (int g = 0; g < 2; ++g) for (int ph = 0; ph < 2; ++ph) {
+                    printf("    group %d phase %d cycles/k-tile:", g, ph);
+                    for (int q = 0; q < 6; ++q) printf("  %s %.0f", part[q], hd[(g * 2 + ph) * 6 + q] / n);
+                    printf("\n");
+                }
+            }
         }
         for (int r = 0; r < rounds; ++r)
             for (size_t vi = 0; vi < variants.size(); ++vi) {

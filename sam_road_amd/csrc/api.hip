@@ -109,6 +109,11 @@ static int run(srh_ctx* c, const char* cls, double flops, double bytes, hipStrea
     return rc;
 }
 
+static bool attn_fused() {
+    static const bool v = !(getenv("SRH_ATTN_FUSED") && atoi(getenv("SRH_ATTN_FUSED")) == 0);
+    return v;
+}
+
 static int gemm(srh_ctx* c, const char* cls, const GemmParams& p, hipStream_t s) {
     const double fl = 2.0 * p.M * (double)p.N * p.K;
     const int rc = run(c, cls, fl, 0.0, s, [&] { return launch_gemm(p, s); });
@@ -422,13 +427,17 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         g.A = c->xn16.as<f16>(); g.lda = D; g.W = b.qkv_w; g.ldw = D; g.M = T; g.N = 3 * D; g.K = D;
         g.bias = b.qkv_b; g.out_f16 = c->qkv16.as<f16>(); g.ldc16 = 3 * D;
         TRY(gemm(c, "gemm_qkv", g, s));
-        RelPosParams rp;
-        rp.qkv = c->qkv16.as<f16>(); rp.ld = 3 * D; rp.table_h = b.rel_h; rp.table_w = b.rel_w;
-        rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = b.win;
-        rp.inv_scale = sqrtf((float)hd);
-        TRYK(c, b.win == S ? "relpos_global" : "relpos_window", 4.0 * T * heads * b.win * hd, 0, s, launch_relpos(rp, s));
         AttnParams ap;
-        ap.qkv = c->qkv16.as<f16>(); ap.ld = 3 * D; ap.rel = c->rel.as<float>(); ap.bias_qkv = b.qkv_b16;
+        ap.table_h = b.rel_h; ap.table_w = b.rel_w;      // rel-pos bias derived inside the attention kernel (fused_relpos)
+        if (!attn_fused()) {                              // A/B aid: separate relpos kernel + [T, heads, 2 Wp] f32 buffer
+            RelPosParams rp;
+            rp.qkv = c->qkv16.as<f16>(); rp.ld = 3 * D; rp.table_h = b.rel_h; rp.table_w = b.rel_w;
+            rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = b.win;
+            rp.inv_scale = sqrtf((float)hd);
+            TRYK(c, b.win == S ? "relpos_global" : "relpos_window", 4.0 * T * heads * b.win * hd, 0, s, launch_relpos(rp, s));
+            ap.rel = c->rel.as<float>();
+        }
+        ap.qkv = c->qkv16.as<f16>(); ap.ld = 3 * D; ap.bias_qkv = b.qkv_b16;
         ap.out = c->attn16.as<f16>(); ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = b.win;
         ap.scale = 1.0f / sqrtf((float)hd);
         TRYK(c, b.win == S ? "attn_global" : "attn_window", attn_flops(B, S, heads, hd, b.win), 0, s, launch_attention(ap, s));
@@ -658,13 +667,17 @@ extern "C" int srh_op_attention(srh_ctx* c, const void* qkv, const void* rel_h, 
     hipStream_t s = (hipStream_t)stream;
     const int hd = 64, D = heads * hd;
     const size_t T = (size_t)B * S * S;
-    if (c->rel.ensure(T * heads * 64 * 4)) return fail(c, SRH_ERR_HIP, "rel workspace allocation failed");
-    RelPosParams rp;
-    rp.qkv = (const f16*)qkv; rp.ld = 3 * D; rp.table_h = (const f16*)rel_h; rp.table_w = (const f16*)rel_w;
-    rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = win; rp.inv_scale = 8.f;
-    TRYK(c, "relpos", 0, 0, s, launch_relpos(rp, s));
     AttnParams ap;
-    ap.qkv = (const f16*)qkv; ap.ld = 3 * D; ap.rel = c->rel.as<float>(); ap.bias_qkv = (const f16*)bias_qkv;
+    ap.table_h = (const f16*)rel_h; ap.table_w = (const f16*)rel_w;     // fused rel-pos bias (default)
+    if (!attn_fused()) {
+        if (c->rel.ensure(T * heads * 64 * 4)) return fail(c, SRH_ERR_HIP, "rel workspace allocation failed");
+        RelPosParams rp;
+        rp.qkv = (const f16*)qkv; rp.ld = 3 * D; rp.table_h = (const f16*)rel_h; rp.table_w = (const f16*)rel_w;
+        rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = win; rp.inv_scale = 8.f;
+        TRYK(c, "relpos", 0, 0, s, launch_relpos(rp, s));
+        ap.rel = c->rel.as<float>();
+    }
+    ap.qkv = (const f16*)qkv; ap.ld = 3 * D; ap.bias_qkv = (const f16*)bias_qkv;
     ap.out = (f16*)out; ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = win; ap.scale = 0.125f;
     TRYK(c, "attention", attn_flops(B, S, heads, hd, win), 0, s, launch_attention(ap, s));
     return 0;

@@ -124,12 +124,14 @@ __device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size
     const f16* q = p.qkv + tok * p.ld + head * HD;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) st.q[ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
-    const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP) + Geom<WIN>::WP;
+    if (p.rel) {
+        const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP) + Geom<WIN>::WP;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int rr, cc;
-        tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
-        st.relw[r] = (cc < WIN) ? rel[cc] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            int rr, cc;
+            tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
+            st.relw[r] = (cc < WIN) ? rel[cc] : 0.f;
+        }
     }
     st.m = -INFINITY;
     st.l = 0.f;
@@ -137,6 +139,53 @@ __device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
+}
+
+// Fused decomposed rel-pos bias (replaces the separate relpos kernel and its [tokens, heads, 2*Wp] f32 round trip
+// through HBM).  For the wave's 32 queries:  P^T[j, q] = T[j, :] . Q[q, :]  over ALL 2*WIN-1 table rows j (one or two
+// 32-row MFMA tiles, A operand = table rows straight from L2, B operand = the query fragments already in registers),
+// then  rel[q, k] = P[q, qc - k + WIN - 1] / scale  is scattered into the wave's LDS table buf[q][k] (row stride STRIDE
+// floats).  The w table goes first: its 16 per-lane values (tile-invariant) are read back into st.relw, then the same
+// buffer is overwritten with the h table, which the key loop reads one or two scalars per tile.
+template <int WIN, int STRIDE>
+__device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, int qy, int qx, float* buf, int lane) {
+    constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
+    const int half = lane >> 5, row = lane & 31;
+    const float inv_scale = 1.0f / p.scale;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {            // 0: w table -> st.relw, 1: h table -> buf
+        const f16* table = pass == 0 ? p.table_w : p.table_h;
+        const int qc = pass == 0 ? qx : qy;
+#pragma unroll
+        for (int jt = 0; jt < NTJ; ++jt) {
+            const int j = jt * 32 + row;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x8 a;
+                if (j < 2 * WIN - 1) a = *reinterpret_cast<const f16x8*>(table + (size_t)j * HD + (ks * 2 + half) * 8);
+                else for (int e = 0; e < 8; ++e) a[e] = (f16)0.f;
+                acc = mfma32(a, st.q[ks], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = qc - (jt * 32 + mfma32_row(r, lane)) + WIN - 1;
+                if (k >= 0 && k < WIN) buf[row * STRIDE + k] = acc[r] * inv_scale;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (pass == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rr, cc;
+                tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
+                st.relw[r] = (cc < WIN) ? buf[row * STRIDE + cc] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 __device__ __forceinline__ void store_query(const QState& st, const AttnParams& p, size_t tok, int head,
@@ -249,14 +298,16 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
         const size_t tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
         QState st;
         load_query<WIN>(st, p, tok, head, lane);
-        // this wave's rel_h table: rh[q][kh], lanes split the 14 values between the two halves
-        {
+        if (p.rel) {
+            // precomputed bias: this wave's rel_h table rh[q][kh], lanes split the 14 values between the two halves
             const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP);
             const int half = lane >> 5;
 #pragma unroll
             for (int e = 0; e < 8; ++e) rh[(lane & 31) * 17 + half * 8 + e] = rel[half * 8 + e];
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            fused_relpos<WIN, 17>(st, p, ry, rx, rh, lane);
         }
-        __builtin_amdgcn_wave_barrier();
         f16x8 kfA[4], kfB[4];
         read_kfrag(kfA, k_lds, lane);
 #pragma unroll 1
@@ -305,11 +356,13 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     QState st;
     load_query<WIN>(st, p, tok, head, lane);
     float* rh = rh_lds + wave * 32 * (WP + 1);
-    {
+    if (p.rel) {
         const float* rel = p.rel + (tok * p.heads + head) * (2 * WP);
         const int half = lane >> 5;
 #pragma unroll
         for (int e = 0; e < WP / 2; ++e) rh[(lane & 31) * (WP + 1) + half * (WP / 2) + e] = rel[half * (WP / 2) + e];
+    } else {
+        fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, lane);
     }
 
     // staging registers (named, not arrays: hipcc keeps lambda-captured staging arrays in scratch):

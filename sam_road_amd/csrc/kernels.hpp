@@ -62,7 +62,9 @@ int launch_relpos(const RelPosParams& p, hipStream_t s);
 // Windowed / global attention with rel-pos bias; pad tokens are real keys with k = b_k, v = b_v.
 struct AttnParams {
     const f16* qkv = nullptr; int ld = 0;   // [tokens, 3*D]: q | k | v, each head-major
-    const float* rel = nullptr;             // from launch_relpos
+    const float* rel = nullptr;             // from launch_relpos; nullptr => fused: the kernel derives the bias from table_h / table_w
+    const f16* table_h = nullptr;           // [2*win-1, hd] fp16 rel-pos tables (fused path)
+    const f16* table_w = nullptr;
     const f16* bias_qkv = nullptr;          // [3*D] fp16 (pad-token k / v rows)
     f16* out = nullptr; int ldo = 0;        // [tokens, D]
     int B = 0, S = 0, heads = 0, hd = 0, win = 0;  // win == S => global

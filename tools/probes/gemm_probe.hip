@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
             diff_kernel<<<1024, 256>>>(ref, s.f16out ? nullptr : o32, s.f16out ? o16 : nullptr, nO, dmax, dmax + 1);
             float h[2]; CK(hipMemcpy(h, dmax, 8, hipMemcpyDeviceToHost));
             printf("  check %-5s variant %3d rc=%d  max|diff|=%.3e  (max|ref|=%.2f)\n", s.name, variants[vi], rc, h[0], h[1]);
-            if (variants[vi] == 53) {
+            if (variants[vi] == 53 || variants[vi] == 55) {
                 unsigned long long hd[32]; CK(hipMemcpy(hd, ddbg, 25 * 8, hipMemcpyDeviceToHost));
                 const double n = (double)hd[24];
                 const char* part[6] = {"issue(reads+dma)", "vmcnt wait", "store+lgkm wait", "barrier1", "mfma seg", "barrier2"};

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="tiles per step per GPU (BASELINE config 2: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="tuning aid: skip the finite-output check (kernel ablations)")
     args = ap.parse_args()
     warnings.simplefilter("ignore")
 
@@ -107,7 +108,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    assert torch.isfinite(scores).all() and torch.isfinite(emb).all()
+    assert args.no_check or (torch.isfinite(scores).all() and torch.isfinite(emb).all())
     tiles_per_s = world * B * args.steps / elapsed
 
     out = {

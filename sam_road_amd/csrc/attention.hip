@@ -15,6 +15,8 @@
 // The rel-pos bias enters as the MFMA accumulator's initial value (f32, pre-divided by scale).
 // Key tiles hold 32 MFMA rows = whole window rows (2 rows of 14 -> 28 valid keys, 2 rows of 16, or
 // 1 row of 32), so the per-lane rel_w values repeat for every tile and rel_h is 1-2 scalars per tile.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -249,77 +251,161 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
     const int wy = widx / nw, wx = widx % nw;
     const int nry = min(WIN, S - wy * WIN), nrx = min(WIN, S - wx * WIN);
     const int nreal = nry * nrx;
+    const int ntq = (nreal + 31) / 32;
+    const int half = lane >> 5;
+    const bool fused = p.rel == nullptr && p.ablate != 3;
 
-    // ---- stage K rows: items (tile, local row i, 16-byte chunk c)
-    for (int it = tid; it < 7 * 32 * 8; it += 256) {
-        const int c = it & 7, i = (it >> 3) & 31, t = it >> 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i < 28) {
-            int rr, cc;
-            tile_rc<WIN>(i, rr, cc);
+    // ---- Every global load of the workgroup is issued up front, so their latencies overlap ONCE: the K / V rows to
+    // stage, the query fragments of this wave's (up to two) query tiles and the rel-pos table fragments.  (Measured
+    // before: the key loop was 23 % of the kernel; staging, per-tile query / table loads and their exposed latencies
+    // were the rest.)
+    // K items: thread (chunk c, local row i) of every tile t = 0..6
+    const int s_c = tid & 7, s_i = (tid >> 3) & 31;
+    uint4 kreg[7];
+    {
+        int rr, cc;
+        tile_rc<WIN>(s_i < 28 ? s_i : 0, rr, cc);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
             const int y = wy * WIN + t * 2 + rr, x = wx * WIN + cc;
-            const f16* src = (y < S && x < S)
-                ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + D + head * HD
-                : p.bias_qkv + D + head * HD;
-            v = *reinterpret_cast<const uint4*>(src + c * 8);
+            const f16* src = (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + D + head * HD
+                                              : p.bias_qkv + D + head * HD;
+            kreg[t] = *reinterpret_cast<const uint4*>(src + s_c * 8);
         }
-        *reinterpret_cast<uint4*>(k_lds + t * 4096 + i * 128 + swz8(i, c) * 16) = v;
     }
-    // ---- stage V^T: items (tile, key quad, d chunk)
-    for (int it = tid; it < 7 * 8 * 8; it += 256) {
-        const int dc = it & 7, kq = (it >> 3) & 7, t = it >> 6;
-        uint4 v[4];
+    // V items: thread (d chunk dc, key quad kq) of tiles t = wave and wave + 4
+    const int s_dc = tid & 7, s_kq = (tid >> 3) & 7;
+    uint4 vreg[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = wave + 4 * j;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int i = kq * 4 + e;
-            v[e] = make_uint4(0, 0, 0, 0);
-            if (i < 28) {
-                int rr, cc;
-                tile_rc<WIN>(i, rr, cc);
-                const int y = wy * WIN + t * 2 + rr, x = wx * WIN + cc;
-                const f16* src = (y < S && x < S)
-                    ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + 2 * D + head * HD
-                    : p.bias_qkv + 2 * D + head * HD;
-                v[e] = *reinterpret_cast<const uint4*>(src + dc * 8);
+            const int i = s_kq * 4 + e;
+            int rr, cc;
+            tile_rc<WIN>(i < 28 ? i : 0, rr, cc);
+            const int y = wy * WIN + min(t, 6) * 2 + rr, x = wx * WIN + cc;
+            const f16* src = (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + 2 * D + head * HD
+                                              : p.bias_qkv + 2 * D + head * HD;
+            vreg[j][e] = *reinterpret_cast<const uint4*>(src + s_dc * 8);
+        }
+    }
+    // query fragments of this wave's tiles jt = wave, wave + 4
+    f16x8 qpre[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qi = min((wave + 4 * j) * 32 + (lane & 31), nreal - 1);
+        const size_t tokq = ((size_t)b * S + wy * WIN + qi / nrx) * S + wx * WIN + qi % nrx;
+        const f16* q = p.qkv + tokq * p.ld + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qpre[j][ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
+    }
+    // rel-pos table fragments (A operand rows j = lane & 31 of the 27-row tables)
+    f16x8 tfrag[2][4];
+    if (fused) {
+        const int j = min(lane & 31, 2 * WIN - 2);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            tfrag[0][ks] = *reinterpret_cast<const f16x8*>(p.table_w + (size_t)j * HD + (ks * 2 + half) * 8);
+            tfrag[1][ks] = *reinterpret_cast<const f16x8*>(p.table_h + (size_t)j * HD + (ks * 2 + half) * 8);
+        }
+    }
+
+    // ---- stage K rows and the transposed, key-permuted V^T tiles
+    if (p.ablate != 2) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const uint4 v = s_i < 28 ? kreg[t] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(k_lds + t * 4096 + s_i * 128 + swz8(s_i, s_c) * 16) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = wave + 4 * j;
+            if (t < 7) {
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                const int i0 = s_kq * 4;
+                vt_write(vt_lds + t * 4096, s_kq, s_dc, i0 < 28 ? vreg[j][0] : z, i0 + 1 < 28 ? vreg[j][1] : z,
+                         i0 + 2 < 28 ? vreg[j][2] : z, i0 + 3 < 28 ? vreg[j][3] : z);
             }
         }
-        vt_write(vt_lds + t * 4096, kq, dc, v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
 
     const float c_exp = p.scale * 1.4426950408889634f;
+    const float inv_scale = 1.0f / p.scale;
     float* rh = rh_lds + wave * 32 * 17;
-    const int ntq = (nreal + 31) / 32;
-    for (int jt = wave; jt < ntq; jt += 4) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int jt = wave + 4 * j;
+        if (jt >= ntq) break;
         const int qi_raw = jt * 32 + (lane & 31);
         const bool valid = qi_raw < nreal;
         const int qi = valid ? qi_raw : nreal - 1;
         const int ry = qi / nrx, rx = qi % nrx;
         const size_t tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
         QState st;
-        load_query<WIN>(st, p, tok, head, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) st.q[ks] = qpre[j][ks];
+        st.m = -INFINITY;
+        st.l = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
         if (p.rel) {
-            // precomputed bias: this wave's rel_h table rh[q][kh], lanes split the 14 values between the two halves
+            // precomputed bias (A/B aid): rel_w per lane, rel_h table rh[q][kh] (lanes split the 14 values between the halves)
             const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP);
-            const int half = lane >> 5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rr, cc;
+                tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
+                st.relw[r] = (cc < WIN) ? rel[Geom<WIN>::WP + cc] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) rh[(lane & 31) * 17 + half * 8 + e] = rel[half * 8 + e];
             __builtin_amdgcn_wave_barrier();
-        } else {
-            fused_relpos<WIN, 17>(st, p, ry, rx, rh, lane);
+        } else if (fused) {
+            // fused rel-pos bias (see fused_relpos): w table -> st.relw, then h table -> rh
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int qc = pass == 0 ? rx : ry;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = mfma32(tfrag[pass][ks], st.q[ks], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jrow = mfma32_row(r, lane);
+                    const int k = qc - jrow + WIN - 1;
+                    if (k >= 0 && k < WIN && jrow < 2 * WIN - 1) rh[(lane & 31) * 17 + k] = acc[r] * inv_scale;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (pass == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int rr, cc;
+                        tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
+                        st.relw[r] = (cc < WIN) ? rh[(lane & 31) * 17 + cc] : 0.f;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
-        f16x8 kfA[4], kfB[4];
-        read_kfrag(kfA, k_lds, lane);
+        if (p.ablate != 1) {
+            f16x8 kfA[4], kfB[4];
+            read_kfrag(kfA, k_lds, lane);
 #pragma unroll 1
-        for (int t = 0; t < 6; t += 2) {     // tiles 0..5 in pairs (next tile's K fragments prefetched), then tile 6
-            float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
-            read_kfrag(kfB, k_lds + (t + 1) * 4096, lane);
-            attn_tile<WIN>(st, kfA, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
-            rh0 = rh[(lane & 31) * 17 + 2 * t + 2]; rh1 = rh[(lane & 31) * 17 + 2 * t + 3];
-            read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
-            attn_tile<WIN>(st, kfB, vt_lds + (t + 1) * 4096, rh0, rh1, c_exp, lane);
+            for (int t = 0; t < 6; t += 2) {     // tiles 0..5 in pairs (next tile's K fragments prefetched), then tile 6
+                float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
+                read_kfrag(kfB, k_lds + (t + 1) * 4096, lane);
+                attn_tile<WIN>(st, kfA, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
+                rh0 = rh[(lane & 31) * 17 + 2 * t + 2]; rh1 = rh[(lane & 31) * 17 + 2 * t + 3];
+                read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
+                attn_tile<WIN>(st, kfB, vt_lds + (t + 1) * 4096, rh0, rh1, c_exp, lane);
+            }
+            attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rh[(lane & 31) * 17 + 12], rh[(lane & 31) * 17 + 13], c_exp, lane);
         }
-        attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rh[(lane & 31) * 17 + 12], rh[(lane & 31) * 17 + 13], c_exp, lane);
         store_query(st, p, tok, head, lane, valid);
         __builtin_amdgcn_wave_barrier();
     }
@@ -411,7 +497,10 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     store_query(st, p, tok, head, lane, true);
 }
 
-int launch_attention(const AttnParams& p, hipStream_t s) {
+int launch_attention(const AttnParams& p_in, hipStream_t s) {
+    static const int env_abl = getenv("SRH_ATTN_ABL") ? atoi(getenv("SRH_ATTN_ABL")) : 0;
+    AttnParams p = p_in;
+    if (!p.ablate) p.ablate = env_abl;
     if (p.hd != HD) return -2;
     if (p.win == p.S) {
         const int grid = p.B * p.heads * (p.S * p.S / 128);

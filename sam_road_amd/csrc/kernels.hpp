@@ -69,6 +69,7 @@ struct AttnParams {
     f16* out = nullptr; int ldo = 0;        // [tokens, D]
     int B = 0, S = 0, heads = 0, hd = 0, win = 0;  // win == S => global
     float scale = 0.125f;
+    int ablate = 0;                         // tuning aid (env SRH_ATTN_ABL): 1 no key loop, 2 no K/V staging, 3 no fused rel-pos
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 

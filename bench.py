@@ -15,7 +15,7 @@ rank runs its own batches — weak scaling, no data-path collective; weights are
 over RCCL before the timed region.  Prints ONE JSON line on rank 0.
 
 The line also carries
-  roofline      — the dominant kernel (the f16 MFMA GEMM, gemm.hip): algorithmic FLOPs of its launches
+  roofline      — the dominant kernel (the f16 MFMA GEMM, gemm_q192.hip / gemm.hip): algorithmic FLOPs of its launches
                   / their summed duration, measured with HIP events on the launch stream in an
                   instrumented pass of the same steps (events around every launch would perturb the
                   headline timing, so they are a separate pass over the same work);
@@ -148,7 +148,7 @@ def main():
                 traffic_src = os.path.relpath(summaries[-1], ROOT)
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "srh::gemm_glds256_kernel / gemm_glds_kernel (f16 MFMA GEMM, all linear layers)",
+        out["roofline"] = {"bound": "mfma", "kernel": "srh::gemm_q192_kernel (persistent 256x192 f16 MFMA GEMM: qkv / proj / fc1 / fc2) + small-layer GEMMs",
                            "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
                            "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(fl / max(n, 1), 1),

@@ -497,11 +497,98 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     store_query(st, p, tok, head, lane, true);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic attention for head dims other than 64 (ViT-H: 80).  Correctness-first fallback: one thread
+// owns one query (q and the output row live in f32 registers), keys are streamed through LDS in chunks
+// of 128 shared by the workgroup's 256 queries, scores / online softmax / P.V on the VALU in f32.
+// Same semantics as the MFMA kernels: pad tokens of a window are real keys with k = b_k, v = b_v, pad
+// queries are skipped, the rel-pos bias comes from the unscaled q and the tables.
+// grid = (image, head, window, block of 256 real queries).
+// ---------------------------------------------------------------------------------------------
+constexpr int GEN_HD = 96, GEN_KC = 128;
+__global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hd = p.hd, win = p.win, S = p.S, nw = (S + win - 1) / win, D = p.heads * hd;
+    f16* k_lds = reinterpret_cast<f16*>(smem);                       // [GEN_KC][hd]
+    f16* v_lds = k_lds + GEN_KC * hd;                                // [GEN_KC][hd]
+    float* rel_lds = reinterpret_cast<float*>(v_lds + GEN_KC * hd);  // [256][2 * win]
+    const int tid = threadIdx.x;
+    const int nqb = (win * win + 255) / 256;
+    int u = blockIdx.x;
+    const int qb = u % nqb; u /= nqb;
+    const int head = u % p.heads; u /= p.heads;
+    const int widx = u % (nw * nw); u /= (nw * nw);
+    const int b = u;
+    const int wy = widx / nw, wx = widx % nw;
+    const int nry = min(win, S - wy * win), nrx = min(win, S - wx * win);
+    const int nreal = nry * nrx;
+    const int qi = qb * 256 + tid;
+    const bool active = qi < nreal;
+    const int ry = active ? qi / nrx : 0, rx = active ? qi % nrx : 0;
+    const size_t tok = ((size_t)b * S + wy * win + ry) * S + wx * win + rx;
+    float q[GEN_HD], o[GEN_HD];
+#pragma unroll
+    for (int d = 0; d < GEN_HD; ++d) { q[d] = (active && d < hd) ? (float)p.qkv[tok * p.ld + head * hd + d] : 0.f; o[d] = 0.f; }
+    // rel-pos bias of this query: rel[k] = q . T[qc - k + win - 1]
+    float* rel = rel_lds + tid * 2 * win;
+    for (int k = 0; k < win; ++k) {
+        const f16* th = p.table_h + (size_t)(ry - k + win - 1) * hd;
+        const f16* tw = p.table_w + (size_t)(rx - k + win - 1) * hd;
+        float ah = 0.f, aw = 0.f;
+#pragma unroll
+        for (int d = 0; d < GEN_HD; ++d) if (d < hd) { ah += q[d] * (float)th[d]; aw += q[d] * (float)tw[d]; }
+        rel[k] = ah; rel[win + k] = aw;
+    }
+    float m = -INFINITY, l = 0.f;
+    const int nkeys = win * win;
+    for (int k0 = 0; k0 < nkeys; k0 += GEN_KC) {
+        const int kc = min(GEN_KC, nkeys - k0);
+        __syncthreads();
+        for (int it = tid; it < kc * (hd / 8); it += 256) {          // stage K / V chunk, 16 bytes per item
+            const int c = it % (hd / 8), kk = k0 + it / (hd / 8);
+            const int y = wy * win + kk / win, x = wx * win + kk % win;
+            const bool real = y < S && x < S;
+            const f16* src = real ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + head * hd : p.bias_qkv + head * hd;
+            *reinterpret_cast<uint4*>(k_lds + (it / (hd / 8)) * hd + c * 8) = *reinterpret_cast<const uint4*>(src + D + c * 8);
+            *reinterpret_cast<uint4*>(v_lds + (it / (hd / 8)) * hd + c * 8) = *reinterpret_cast<const uint4*>(src + 2 * D + c * 8);
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (int j = 0; j < kc; ++j) {
+            const int kk = k0 + j;
+            float sdot = 0.f;
+#pragma unroll
+            for (int d = 0; d < GEN_HD; ++d) if (d < hd) sdot += q[d] * (float)k_lds[j * hd + d];
+            const float sc = sdot * p.scale + rel[kk / win] + rel[win + kk % win];
+            const float m_new = fmaxf(m, sc);
+            const float alpha = __expf(m - m_new), pe = __expf(sc - m_new);
+            l = l * alpha + pe;
+#pragma unroll
+            for (int d = 0; d < GEN_HD; ++d) if (d < hd) o[d] = o[d] * alpha + pe * (float)v_lds[j * hd + d];
+            m = m_new;
+        }
+    }
+    if (!active) return;
+    const float inv = 1.0f / l;
+    for (int d = 0; d < hd; ++d) p.out[tok * p.ldo + head * hd + d] = (f16)(o[d] * inv);
+}
+
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
     static const int env_abl = getenv("SRH_ATTN_ABL") ? atoi(getenv("SRH_ATTN_ABL")) : 0;
     AttnParams p = p_in;
     if (!p.ablate) p.ablate = env_abl;
-    if (p.hd != HD) return -2;
+    if (p.hd != HD) {
+        if (p.hd > GEN_HD || p.hd % 8 || !p.table_h || !p.table_w || p.win > 32) return -2;
+        const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
+        const int lds = 2 * GEN_KC * p.hd * 2 + 256 * 2 * p.win * 4;
+        static bool gattr = false;
+        if (!gattr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            gattr = true;
+        }
+        hipLaunchKernelGGL(attn_generic_kernel, dim3(p.B * nw * nw * p.heads * nqb), dim3(256), lds, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (p.win == p.S) {
         const int grid = p.B * p.heads * (p.S * p.S / 128);
         if (p.S == 32) hipLaunchKernelGGL(attn_global_kernel<32>, dim3(grid), dim3(256), 0, s, p);

@@ -37,12 +37,16 @@ def rel_l2(a, b):
 
 CFG512 = dict(SAM_VERSION="vit_b", PATCH_SIZE=512, TOPONET_VERSION="normal", SAM_CKPT_PATH="")
 CFG256 = dict(SAM_VERSION="vit_b", PATCH_SIZE=256, TOPONET_VERSION="normal", SAM_CKPT_PATH="")
+CFG_L256 = dict(SAM_VERSION="vit_l", PATCH_SIZE=256, TOPONET_VERSION="normal", SAM_CKPT_PATH="")
+CFG_H256 = dict(SAM_VERSION="vit_h", PATCH_SIZE=256, TOPONET_VERSION="normal", SAM_CKPT_PATH="")   # toponet_vith_256.yaml (BASELINE configs[4])
 
 
 @pytest.mark.parametrize("cfg,B,depth,gidx", [
     (CFG512, 2, 1, []),        # one windowed block
     (CFG512, 1, 1, [0]),       # one global block
     (CFG256, 2, 2, [1]),       # 256 tile: windowed + global(16)
+    (CFG_L256, 1, 2, [1]),     # ViT-L: D = 1024, 16 heads x 64
+    (CFG_H256, 2, 2, [1]),     # ViT-H: D = 1280, 16 heads x 80 (generic attention kernel)
 ])
 def test_shallow_encoder_parity(cfg, B, depth, gidx):
     cfg = dict(cfg, ENCODER_DEPTH=depth, ENCODER_GLOBAL_ATTN_INDEXES=gidx)

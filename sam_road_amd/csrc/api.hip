@@ -218,7 +218,7 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
     if (hd % 8 || hd > 96) return fail(c, SRH_ERR_UNSUPPORTED, "head_dim must be a multiple of 8 and <= 96");   // 64: MFMA kernels, 80 (ViT-H): generic kernel
     if (cfg->patch_size % 16) return fail(c, SRH_ERR_BAD_ARG, "PATCH_SIZE must be a multiple of 16");
     const int S = cfg->patch_size / 16;
-    if (S != 16 && S != 32) return fail(c, SRH_ERR_UNSUPPORTED, "PATCH_SIZE must be 256 or 512");
+    if (S != 16 && S != 32 && S != 64) return fail(c, SRH_ERR_UNSUPPORTED, "PATCH_SIZE must be 256, 512 or 1024");
     if (cfg->window_size != 14) return fail(c, SRH_ERR_UNSUPPORTED, "window_size must be 14");
     if (D % 128 || (D != 768 && D != 1024 && D != 1280)) return fail(c, SRH_ERR_UNSUPPORTED, "embed_dim must be 768, 1024 or 1280");
     hipSetDevice(c->device);

@@ -509,9 +509,10 @@ constexpr int GEN_HD = 96, GEN_KC = 128;
 __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int hd = p.hd, win = p.win, S = p.S, nw = (S + win - 1) / win, D = p.heads * hd;
-    f16* k_lds = reinterpret_cast<f16*>(smem);                       // [GEN_KC][hd]
-    f16* v_lds = k_lds + GEN_KC * hd;                                // [GEN_KC][hd]
-    float* rel_lds = reinterpret_cast<float*>(v_lds + GEN_KC * hd);  // [256][2 * win]
+    const int KC = win > 32 ? GEN_KC / 2 : GEN_KC;                    // keys per LDS chunk (the rel table grows with win)
+    f16* k_lds = reinterpret_cast<f16*>(smem);                       // [KC][hd]
+    f16* v_lds = k_lds + KC * hd;                                    // [KC][hd]
+    float* rel_lds = reinterpret_cast<float*>(v_lds + KC * hd);      // [256][2 * win]
     const int tid = threadIdx.x;
     const int nqb = (win * win + 255) / 256;
     int u = blockIdx.x;
@@ -541,8 +542,8 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     }
     float m = -INFINITY, l = 0.f;
     const int nkeys = win * win;
-    for (int k0 = 0; k0 < nkeys; k0 += GEN_KC) {
-        const int kc = min(GEN_KC, nkeys - k0);
+    for (int k0 = 0; k0 < nkeys; k0 += KC) {
+        const int kc = min(KC, nkeys - k0);
         __syncthreads();
         for (int it = tid; it < kc * (hd / 8); it += 256) {          // stage K / V chunk, 16 bytes per item
             const int c = it % (hd / 8), kk = k0 + it / (hd / 8);
@@ -577,10 +578,12 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     static const int env_abl = getenv("SRH_ATTN_ABL") ? atoi(getenv("SRH_ATTN_ABL")) : 0;
     AttnParams p = p_in;
     if (!p.ablate) p.ablate = env_abl;
-    if (p.hd != HD) {
-        if (p.hd > GEN_HD || p.hd % 8 || !p.table_h || !p.table_w || p.win > 32) return -2;
+    const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32)));
+    if (!mfma_path) {      // other head dims (ViT-H) and the 64x64 global window of 1024-pixel tiles
+        if (p.hd > GEN_HD || p.hd % 8 || !p.table_h || !p.table_w || p.win > 64) return -2;
         const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
-        const int lds = 2 * GEN_KC * p.hd * 2 + 256 * 2 * p.win * 4;
+        const int lds = 2 * (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 2 + 256 * 2 * p.win * 4;
+        if (lds > 160 * 1024) return -2;
         static bool gattr = false;
         if (!gattr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

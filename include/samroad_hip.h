@@ -137,6 +137,14 @@ typedef struct {
 int srh_profile_enable(srh_ctx* ctx, int on);
 int srh_profile_read(srh_ctx* ctx, srh_profile_row* rows, int max_rows, int* n_rows);
 
+/* ---- host-side geometry between the two GPU passes (no device work, callable without a GPU) ---------------
+ * Greedy radius NMS of reference graph_utils.py:572-591 (nms_points), the step that turns the fused masks into
+ * graph points (graph_extraction.py:130-139).  Candidates are given ALREADY in the reference's processing order
+ * (np.argsort(scores)[::-1], computed by the caller so numpy's tie order is kept): xy int32 [n,2] (x,y),
+ * force[i] = (score_i > 1.0).  Writes kept[i] in {0,1}.  Exact integer arithmetic, identical result to the
+ * reference's KDTree loop. */
+int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int32_t radius, uint8_t* kept);
+
 #ifdef __cplusplus
 }
 #endif

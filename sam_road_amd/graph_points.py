@@ -4,8 +4,11 @@ Mirrors reference graph_extraction.py:24-28,130-139 and graph_utils.py:572-591. 
 "next" row of SURVEY.md §8(f) (rank 2): it stays on the host as in the reference; the greedy NMS is
 order-dependent, so the candidate order (descending score, np.argsort tie order) is kept identical.
 """
+import ctypes as C
+
 import numpy as np
-import scipy.spatial
+
+from . import _lib
 
 
 def points_and_scores_from_mask(mask, threshold):
@@ -15,19 +18,25 @@ def points_and_scores_from_mask(mask, threshold):
 
 
 def nms_points(points, scores, radius, return_indices=False):
-    """Greedy radius suppression in descending score order; a score > 1.0 is always kept."""
+    """Greedy radius suppression in descending score order; a score > 1.0 is always kept.
+    The candidate order is numpy's (np.argsort tie order, as in the reference); the suppression loop itself — a
+    Python loop over a KDTree in the reference, ~1 s per CityScale scene — runs in the library's host code
+    (srh_nms_points_host, csrc/host_geom.hip: same algorithm on a uniform grid, exact integer distances)."""
     order = np.argsort(scores)[::-1]
     pts, sc = points[order, :], scores[order]
-    kept = np.ones(order.shape[0], dtype=bool)
-    if pts.shape[0]:
-        tree = scipy.spatial.cKDTree(pts)
-        force = sc > 1.0
-        for i in range(pts.shape[0]):
-            if not kept[i]:
-                continue
-            nbr = tree.query_ball_point(pts[i], r=radius)
-            kept[nbr] = force[nbr]
-            kept[i] = True
+    n = int(order.shape[0])
+    kept = np.ones(n, dtype=np.uint8)
+    if n:
+        if not np.issubdtype(pts.dtype, np.integer) or float(radius) != int(radius):
+            raise TypeError("nms_points: integer pixel coordinates and an integer radius are expected "
+                            "(np.where of the u8 masks, *_NMS_RADIUS of the YAMLs)")
+        xy = np.ascontiguousarray(pts, dtype=np.int32)
+        force = np.ascontiguousarray(sc > 1.0, dtype=np.uint8)
+        rc = _lib.load().srh_nms_points_host(xy.ctypes.data_as(C.c_void_p), force.ctypes.data_as(C.c_void_p), n,
+                                             int(radius), kept.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise _lib.SrhError(f"srh_nms_points_host failed ({rc})")
+    kept = kept.astype(bool)
     if return_indices:
         return pts[kept], order[kept]
     return pts[kept]

@@ -49,6 +49,19 @@ def test_nms_points_matches_reference_golden(golden_dir):
     assert nms_points(np.zeros((0, 2), np.int64), np.zeros((0,)), 8).shape == (0, 2)   # empty input
 
 
+@pytest.mark.parametrize("seed,n,radius,forced_frac", [(0, 3000, 8, 0.0), (1, 3000, 16, 0.05), (2, 500, 3, 0.5),
+                                                       (3, 2000, 16, 1.0), (4, 1, 8, 0.0), (5, 4000, 1, 0.0)])
+def test_nms_points_host_code_matches_oracle_loop(seed, n, radius, forced_frac):
+    """srh_nms_points_host (grid, C++) against the oracle's literal KDTree loop (reference graph_utils.py:572-591) on
+    dense integer candidates with heavy score ties, forced (> 1.0) scores, duplicates and boundary distances."""
+    from oracle import scene as oscene
+    rng = np.random.default_rng(seed)
+    pts = rng.integers(0, 120, size=(n, 2)).astype(np.int64)          # dense: many neighbours, duplicate points
+    sc = rng.integers(0, 4, size=n).astype(np.float64) / 4.0             # ties; all <= 1.0
+    sc[rng.random(n) < forced_frac] = 200.0                              # forced candidates (u8-mask-like scores)
+    np.testing.assert_array_equal(nms_points(pts, sc, radius), oscene.nms_points(pts, sc, radius))
+
+
 def test_extract_graph_points_and_queries():
     rng = np.random.default_rng(0)
     kp = (rng.random((256, 256)) ** 8 * 255).astype(np.uint8)

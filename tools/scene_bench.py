@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Scene-level timing (BASELINE configs[3], one GPU): one synthetic 2048x2048 u8 scene (2 km x 2 km at 1 m/px),
+toponet_vitb_512_cityscale.yaml tiling (SAMPLE_MARGIN 64, 16x16 = 256 tiles of 512^2), seeded random weights.
+Reports ms per scene for pass 1 alone (crop -> encoder -> decoder -> fused u8 masks, all on the GPU) and for the
+whole infer_one_img (pass 1 + host NMS + pass-2 queries + TopoNet + edge vote).  The final map_decoder bias is
+lowered so that the random network yields sparse masks (a few thousand graph points, as a trained one does).
+
+    python tools/scene_bench.py [--bias -2.2] [--batch 64] [--iters 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bias", type=float, default=-2.2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--wscale", type=float, default=0.5)
+    args = ap.parse_args()
+    from sam_road_amd import Config, SAMRoad
+    from sam_road_amd.inferencer import infer_one_img
+    from sam_road_amd.tiling import get_patch_info_one_img
+    cfg = Config(SAM_VERSION="vit_b", PATCH_SIZE=512, TOPONET_VERSION="normal", SAM_CKPT_PATH="", DATASET="cityscale",
+                 INFER_BATCH_SIZE=args.batch, SAMPLE_MARGIN=64, INFER_PATCHES_PER_EDGE=16, ITSC_THRESHOLD=0.248,
+                 ROAD_THRESHOLD=0.364, TOPO_THRESHOLD=0.499, ITSC_NMS_RADIUS=8, ROAD_NMS_RADIUS=16, NEIGHBOR_RADIUS=64,
+                 MAX_NEIGHBOR_QUERIES=16)
+    net = SAMRoad(cfg)
+    g = torch.Generator().manual_seed(1234)
+    sd = {}
+    for k, v in net.state_dict().items():
+        if v.dim() == 1 and k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            sd[k] = 0.02 * torch.randn(v.shape, generator=g)
+    sd["map_decoder.7.weight"] = args.wscale * torch.randn(sd["map_decoder.7.weight"].shape, generator=g)
+    sd["map_decoder.7.bias"] = torch.full_like(sd["map_decoder.7.bias"], args.bias)
+    net.load_state_dict(sd, strict=True)
+    net.eval().to("cuda")
+    rng = np.random.default_rng(0)
+    coarse = rng.integers(0, 256, size=(2048 // 8, 2048 // 8, 3)).astype(np.float32)
+    img = np.kron(coarse, np.ones((8, 8, 1), np.float32)).astype(np.uint8)
+
+    infos = get_patch_info_one_img(0, 2048, cfg.SAMPLE_MARGIN, cfg.PATCH_SIZE, cfg.INFER_PATCHES_PER_EDGE)
+    xy = torch.as_tensor(np.array([[p[1][0], p[1][1]] for p in infos], dtype=np.int32)).cuda()
+    scene = torch.as_tensor(img).cuda()
+
+    def pass1():
+        kp, road, emb = net.scene_pass1(scene, xy, args.batch)
+        kpu, ru = net.scene_normalise(kp, road, xy)
+        return kpu.cpu(), ru.cpu()
+
+    pass1()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        pass1()
+    torch.cuda.synchronize()
+    p1 = (time.perf_counter() - t0) / args.iters
+    # host-stage split: wrap the two host-side stages with timers
+    import sam_road_amd.inferencer as inf
+    acc = {"extract_graph_points": 0.0, "edge_votes": 0.0}
+    def timed(name, fn):
+        def w(*a, **k):
+            torch.cuda.synchronize(); t = time.perf_counter(); r = fn(*a, **k); torch.cuda.synchronize()
+            acc[name] += time.perf_counter() - t
+            return r
+        return w
+    inf.extract_graph_points = timed("extract_graph_points", inf.extract_graph_points)
+    inf.edge_votes = timed("edge_votes", inf.edge_votes)
+    res = infer_one_img(net, img, cfg)
+    for k in acc: acc[k] = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        res = infer_one_img(net, img, cfg)
+    torch.cuda.synchronize()
+    full = (time.perf_counter() - t0) / args.iters
+    nodes, edges, kp, road = res
+    print(json.dumps({"scene": "synthetic 2048x2048 u8, 256 tiles of 512^2 (16x16, margin 64)", "n_gpus": 1,
+                      "infer_batch_size": args.batch, "ms_per_scene_pass1": round(1e3 * p1, 2),
+                      "tiles_per_s_pass1": round(256 / p1, 1), "ms_per_scene_full": round(1e3 * full, 2),
+                      "ms_extract_graph_points": round(1e3 * acc["extract_graph_points"] / args.iters, 2),
+                      "ms_edge_votes": round(1e3 * acc["edge_votes"] / args.iters, 2), "graph_points": int(nodes.shape[0]), "edges": int(edges.shape[0]),
+                      "kp_mask_frac": float((kp > cfg.ITSC_THRESHOLD * 255).mean()),
+                      "road_mask_frac": float((road > cfg.ROAD_THRESHOLD * 255).mean())}))
+
+
+if __name__ == "__main__":
+    main()

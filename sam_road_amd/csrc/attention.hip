@@ -219,12 +219,15 @@ __device__ __forceinline__ void vt_write(char* vt, int kq, int dc, const uint4& 
                                          const uint4& v2, const uint4& v3) {
     const int slot = vt_slot(kq * 4);
     const int c = slot >> 3, eo = slot & 7;   // eo is 0 or 4
+    // 4 keys x 8 dims -> 8 dims x 4 keys: every output word pairs the same fp16 of two keys = ONE v_perm_b32
+    // (byte select 0x05040100: low halves, 0x07060302: high halves) instead of shift / and / or chains
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int d = dc * 8 + e;
+        const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
         uint2 w;
-        w.x = u4_half(v0, e) | (u4_half(v1, e) << 16);
-        w.y = u4_half(v2, e) | (u4_half(v3, e) << 16);
+        w.x = __builtin_amdgcn_perm(u4_word(v1, e >> 1), u4_word(v0, e >> 1), sel);
+        w.y = __builtin_amdgcn_perm(u4_word(v3, e >> 1), u4_word(v2, e >> 1), sel);
         *reinterpret_cast<uint2*>(vt + d * 64 + ((c ^ ((d >> 2) & 3)) * 16) + eo * 2) = w;
     }
 }
@@ -477,9 +480,9 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     for (int sidx = 0; sidx < NSTAGE; ++sidx) {
         const int buf = sidx & 1;
         const int snext = sidx + 1 < NSTAGE ? sidx + 1 : sidx;   // last stage re-loads itself (no branch)
-        SRH_LOAD_STAGE(snext)
+        if (p.ablate != 2) SRH_LOAD_STAGE(snext)
         const char* base = smem + buf * STAGE;
-        {
+        if (p.ablate != 1) {
             f16x8 kfA[4], kfB[4];
             read_kfrag(kfA, base, lane);
             read_kfrag(kfB, base + 4096, lane);
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
             rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + (t0 + 1) * RPT + 1] : 0.f;
             attn_tile<WIN>(st, kfB, base + 8192 + 4096, rh0, rh1, c_exp, lane);
         }
-        SRH_STORE_STAGE(buf ^ 1)
+        if (p.ablate != 2) SRH_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
     store_query(st, p, tok, head, lane, true);

@@ -72,8 +72,10 @@ __device__ __forceinline__ void q_wait_vm(int n) {      // wave-uniform n
     }
 }
 
-// SCH 0: ds_reads retired (lgkmcnt 0) BEFORE a phase's first barrier, DMA issued two phases ahead of its wait.
-// SCH 1: ds_read latency overlaps the barrier (lgkmcnt 0 after it), DMA issued one phase ahead of its wait.
+// SCH 0: LDS-DMA pieces issued in the ds_read segments (two phases ahead of their wait), none past the last k-tile.
+// SCH 1: LDS-DMA pieces issued INSIDE the MFMA segments (between the matrix instructions; 1.5 phases ahead of their
+//        wait) and unconditionally (the last two steps prefetch k-tiles nobody reads) — the ds_read segment, which
+//        paces the loop, sheds the DMA issue and all its scalar bookkeeping / tail branches.
 template <int ABL, int ACT, bool BIAS, int SCH>   // ABL ablation aid: 0 normal, 1 no epilogue stores, 2 no MFMA; ACT 0 none / 1 GELU / 2 ReLU
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_q192_kernel(GemmParams p) {
@@ -161,7 +163,8 @@ void gemm_q192_kernel(GemmParams p) {
     // ---- prologue: k-tiles 0 and 1 of the first tile (X1(1) is issued by P0 of step 0)
     Q_ISSUE_A(0)
     Q_ISSUE_B(0)
-    if (SCH == 0) { Q_ISSUE_A(1) q_wait_vm(7); } else q_wait_vm(0);
+    Q_ISSUE_A(1)
+    q_wait_vm(7);
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();                     // stagger: group 1 runs one segment behind group 0
 
@@ -173,11 +176,12 @@ void gemm_q192_kernel(GemmParams p) {
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { xf[mt][0] = *reinterpret_cast<const f16x8*>(xad0 + (b) * Q_XBUF + (off) + mt * 2048); \
                                                         xf[mt][1] = *reinterpret_cast<const f16x8*>(xad1 + (b) * Q_XBUF + (off) + mt * 2048); } }
     // MFMA builtins are pure register ops: pin them between the segment barriers through their operands
-#define Q_MMA(h, EPI) { \
+#define Q_MMA(h, EPI, DMA) { \
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) { asm volatile("" : "+v"(wf[nt][0])); asm volatile("" : "+v"(wf[nt][1])); } \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(xf[mt][0])); asm volatile("" : "+v"(xf[mt][1])); } \
     if (ABL != 2) { \
     __builtin_amdgcn_s_setprio(1); \
+    DMA \
     EPI \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) \
@@ -248,24 +252,23 @@ void gemm_q192_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
-                    if (more1) Q_ISSUE_A(b ^ 1)
                     __builtin_amdgcn_sched_barrier(0);
                     Q_TICK(0, 0)
-                    // X1(s) (issued in P1 of the previous step) has landed; younger: this segment's store and A(s+1) 5 (+ bias)
-                    if (!more1) q_wait_vm(0);
-                    else {
-                        const int nst = kk >= 1 ? 1 : 0;
+                    // X1(s) (issued in the MFMA segment of P0(s-1)) has landed; younger: A(s+1) 5 (+ bias) and two stores
+                    {
+                        const int nst = kk >= 1 ? 2 : 0;
                         if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(6 + nst); else q_wait_vm(6); }
                         else { if (tr) q_wait_vm(5 + nst); else q_wait_vm(5); }
                     }
                     Q_TICK(0, 1)
                     __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 Q_TICK(0, 2)
                 Q_SEG_BARRIER()
-                if (SCH == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 Q_TICK(0, 3)
-                Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend))
+                if (SCH == 0) Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend), )
+                else Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend), Q_ISSUE_B(b ^ 1))
                 Q_TICK(0, 4)
                 Q_SEG_BARRIER()
                 Q_TICK(0, 5)
@@ -288,20 +291,19 @@ void gemm_q192_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
-                    if (more1) Q_ISSUE_B(b ^ 1)
                     __builtin_amdgcn_sched_barrier(0);
                     Q_TICK(1, 0)
-                    // W, X0(s+1) (issued in P0 of this step) landed; younger: this segment's store and X1(s+1) 2
-                    if (!more1) q_wait_vm(0);
-                    else { if (tr) q_wait_vm(3); else q_wait_vm(2); }
+                    // W, X0(s+1) (issued in the MFMA segment of P1(s-1)) landed; younger: X1(s+1) 2 and two stores
+                    if (tr) q_wait_vm(kk >= 1 ? 4 : 3); else q_wait_vm(2);
                     Q_TICK(1, 1)
                     __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 Q_TICK(1, 2)
                 Q_SEG_BARRIER()
-                if (SCH == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 Q_TICK(1, 3)
-                Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend))
+                if (SCH == 0) Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend), )
+                else Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend), Q_ISSUE_A(b))
                 Q_TICK(1, 4)
                 Q_SEG_BARRIER()
                 Q_TICK(1, 5)
@@ -340,6 +342,7 @@ void gemm_q192_kernel(GemmParams p) {
     // image in the now idle operand LDS — one [128 rows][384 B] slab per group — and write it out as full 384-byte
     // rows, 16 bytes per lane (8 rows = 3 KiB = three instructions).
     if (pend) { Q_EPI_STORE(23, rpend) pend = false; }
+    if (SCH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unconditional prefetches of the last two steps
     __syncthreads();                                              // every wave is done reading operand slabs
     char* const slab = smem + g * 49152;
 #pragma unroll

@@ -55,6 +55,38 @@ def test_gemm(ctx, M, N, K, act, resid):
     assert (o16.cpu().float() - ref).abs().max().item() <= 2e-3 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("M,N,K,act,use_bias", [
+    (8192, 768, 768, 0, True),        # 128 tiles, one per workgroup: only the exposed (LDS-staged) epilogue
+    (16384, 2304, 768, 1, True),      # 768 tiles = 3 per workgroup: deferred epilogue with GELU riding the next tile
+    (16384, 768, 3072, 2, False),     # 48 k-tiles per tile (four 12-k-tile blocks), ReLU, no bias
+    (12288, 1536, 768, 0, True),      # 384 tiles on 256 workgroups: some walk two tiles, some one
+])
+def test_gemm_persistent_q192(ctx, M, N, K, act, use_bias):
+    """The persistent 256x192 kernel (csrc/gemm_q192.hip) is selected for large fp16-output problems; compare with a plain
+    fp32 torch matmul of the same fp16 operands.  Tolerance: fp16 output of a value rounded to fp16 once before bias /
+    activation and once after -> 2 fp16 ulps of the largest magnitude."""
+    g = torch.Generator().manual_seed(M + N + K + act)
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    A[:, 0] += (torch.arange(M, device="cuda") % 64).half() * 0.01   # row-dependent structure: catches transposed / permuted writes
+    W[:, 1] += (torch.arange(N, device="cuda") % 48).half() * 0.01
+    bias = torch.randn(N, generator=g).cuda() if use_bias else None
+    ref = A.float() @ W.float().t()
+    if use_bias:
+        ref = ref + bias
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    o16 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(A), _p(W), _p(bias), None, M, N, K, act, None, _p(o16), None), "srh_op_gemm")
+    _sync()
+    assert torch.isfinite(o16).all()
+    err = (o16.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2.5e-3 * max(scale, 1.0), (err, scale)
+
+
 def test_gemm_inplace_residual(ctx):
     M, N, K = 384, 256, 128
     g = torch.Generator().manual_seed(5)

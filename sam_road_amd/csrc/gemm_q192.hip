@@ -72,11 +72,9 @@ __device__ __forceinline__ void q_wait_vm(int n) {      // wave-uniform n
     }
 }
 
-// SCH 0: LDS-DMA pieces issued in the ds_read segments (two phases ahead of their wait), none past the last k-tile.
-// SCH 1: LDS-DMA pieces issued INSIDE the MFMA segments (between the matrix instructions; 1.5 phases ahead of their
-//        wait) and unconditionally (the last two steps prefetch k-tiles nobody reads) — the ds_read segment, which
-//        paces the loop, sheds the DMA issue and all its scalar bookkeeping / tail branches.
-template <int ABL, int ACT, bool BIAS, int SCH>   // ABL ablation aid: 0 normal, 1 no epilogue stores, 2 no MFMA; ACT 0 none / 1 GELU / 2 ReLU
+// SCH 0: two barriers per phase, the groups' read and MFMA segments strictly paired (the MI355X guide's template).
+// SCH 1: one barrier per phase, the groups run their read / MFMA segments in opposite order (see the loop).
+template <int ABL, int ACT, bool BIAS, int SCH>   // ABL ablation aid: 0 normal, 1 no epilogue stores, 2 no MFMA, 3 segment timing, 4 no DMA in the loop; ACT 0 none / 1 GELU / 2 ReLU
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_q192_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,15 +162,21 @@ void gemm_q192_kernel(GemmParams p) {
     Q_ISSUE_A(0)
     Q_ISSUE_B(0)
     Q_ISSUE_A(1)
-    q_wait_vm(7);
+    if (SCH == 1 && g == 1) q_wait_vm(5); else q_wait_vm(7);     // SCH 1: group 1 never waits for group(1) = X1(0) again
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();                     // stagger: group 1 runs one segment behind group 0
 
     f16x8 wf[3][2], xf[4][2];
-#define Q_RDW(b) { \
+    if (ABL == 5) {      // ablation: no fragment ds_reads (operands stay whatever the registers hold)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { wf[i][0] = f16x8{1, 1, 1, 1, 1, 1, 1, 1}; wf[i][1] = wf[i][0]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xf[i][0] = f16x8{1, 1, 1, 1, 1, 1, 1, 1}; xf[i][1] = xf[i][0]; }
+    }
+#define Q_RDW(b) if (ABL != 5) { \
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) { wf[nt][0] = *reinterpret_cast<const f16x8*>(wad0 + (b) * Q_WBUF + nt * 2048); \
                                                         wf[nt][1] = *reinterpret_cast<const f16x8*>(wad1 + (b) * Q_WBUF + nt * 2048); } }
-#define Q_RDX(b, off) { \
+#define Q_RDX(b, off) if (ABL != 5) { \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { xf[mt][0] = *reinterpret_cast<const f16x8*>(xad0 + (b) * Q_XBUF + (off) + mt * 2048); \
                                                         xf[mt][1] = *reinterpret_cast<const f16x8*>(xad1 + (b) * Q_XBUF + (off) + mt * 2048); } }
     // MFMA builtins are pure register ops: pin them between the segment barriers through their operands
@@ -228,6 +232,7 @@ void gemm_q192_kernel(GemmParams p) {
             for (int kk = 0; kk < 12; ++kk, --s_left) {
                 const int b = kk & 1;            // == global step parity (nk and kb are even)
                 const bool more1 = s_left > 1, more2 = s_left > 2;
+              if (SCH == 0) {
                 // ================= P0: W x X0          (epilogue step I = 2 kk: bias read here, math inside the MFMA
                 f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};   //  segment, store in the next ds_read segment)
                 Q_EPI_BIAS(2 * kk, bias4)
@@ -237,38 +242,23 @@ void gemm_q192_kernel(GemmParams p) {
                 // until the TA has worked them off (measured: ~400 clk behind five pieces)
                 if (kk == 0) { if (pend) Q_EPI_STORE(23, rpend) pend = false; }
                 else if (tr) Q_EPI_STORE(2 * kk - 1, rpend)
-                if (SCH == 0) {
-                    if (more1) Q_ISSUE_B(b ^ 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                    Q_TICK(0, 0)
-                    // X1(s) has landed; younger: A(s+1) 5 (+ bias), X1(s+1) 2, and the epilogue stores of this and the last segment
-                    if (!more1) q_wait_vm(0);
-                    else {
-                        const int nst = kk >= 1 ? 2 : 0;
-                        if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
-                        else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
-                    }
-                    Q_TICK(0, 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-                    Q_TICK(0, 0)
-                    // X1(s) (issued in the MFMA segment of P0(s-1)) has landed; younger: A(s+1) 5 (+ bias) and two stores
-                    {
-                        const int nst = kk >= 1 ? 2 : 0;
-                        if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(6 + nst); else q_wait_vm(6); }
-                        else { if (tr) q_wait_vm(5 + nst); else q_wait_vm(5); }
-                    }
-                    Q_TICK(0, 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ABL != 4 && more1) Q_ISSUE_B(b ^ 1)
+                __builtin_amdgcn_sched_barrier(0);
+                Q_TICK(0, 0)
+                // X1(s) has landed; younger: A(s+1) 5 (+ bias), X1(s+1) 2, and the epilogue stores of this and the last segment
+                if (!more1) q_wait_vm(0);
+                else {
+                    const int nst = kk >= 1 ? 2 : 0;
+                    if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
+                    else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
                 }
+                Q_TICK(0, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 Q_TICK(0, 2)
                 Q_SEG_BARRIER()
                 Q_TICK(0, 3)
-                if (SCH == 0) Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend), )
-                else Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend), Q_ISSUE_B(b ^ 1))
+                Q_MMA(0, Q_EPI_COMPUTE(2 * kk, bias4, rpend), )
                 Q_TICK(0, 4)
                 Q_SEG_BARRIER()
                 Q_TICK(0, 5)
@@ -276,37 +266,84 @@ void gemm_q192_kernel(GemmParams p) {
                 Q_EPI_BIAS(2 * kk + 1, bias4)
                 Q_RDX(b, Q_X1)
                 if (tr) Q_EPI_STORE(2 * kk, rpend)
-                if (SCH == 0) {
-                    if (more2) Q_ISSUE_A(b)
-                    __builtin_amdgcn_sched_barrier(0);
-                    Q_TICK(1, 0)
-                    // W, X0(s+1) landed; younger: X1(s+1) 2, A(s+2) 5 (+ bias), and the epilogue stores of this and the last segment
-                    if (!more2) { if (!more1) q_wait_vm(0); else if (tr) q_wait_vm(4); else q_wait_vm(2); }
-                    else {
-                        const int nst = kk >= 1 ? 2 : 1;
-                        if (BIAS && kk == 10 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
-                        else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
-                    }
-                    Q_TICK(1, 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-                    Q_TICK(1, 0)
-                    // W, X0(s+1) (issued in the MFMA segment of P1(s-1)) landed; younger: X1(s+1) 2 and two stores
-                    if (tr) q_wait_vm(kk >= 1 ? 4 : 3); else q_wait_vm(2);
-                    Q_TICK(1, 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ABL != 4 && more2) Q_ISSUE_A(b)
+                __builtin_amdgcn_sched_barrier(0);
+                Q_TICK(1, 0)
+                // W, X0(s+1) landed; younger: X1(s+1) 2, A(s+2) 5 (+ bias), and the epilogue stores of this and the last segment
+                if (!more2) { if (!more1) q_wait_vm(0); else if (tr) q_wait_vm(4); else q_wait_vm(2); }
+                else {
+                    const int nst = kk >= 1 ? 2 : 1;
+                    if (BIAS && kk == 10 && lastblk) { if (tr) q_wait_vm(8 + nst); else q_wait_vm(8); }
+                    else { if (tr) q_wait_vm(7 + nst); else q_wait_vm(7); }
                 }
+                Q_TICK(1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 Q_TICK(1, 2)
                 Q_SEG_BARRIER()
                 Q_TICK(1, 3)
-                if (SCH == 0) Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend), )
-                else Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend), Q_ISSUE_A(b))
+                Q_MMA(1, Q_EPI_COMPUTE(2 * kk + 1, bias4, rpend), )
                 Q_TICK(1, 4)
                 Q_SEG_BARRIER()
                 Q_TICK(1, 5)
+              } else {
+                // ---------------------------------------------------------------------------------------------------
+                // SCH 1: ONE barrier per phase.  Between two barriers group 1 runs [DMA issue, reads(k), mma(k)] while
+                // group 0 runs [DMA issue, mma(k), reads(k+1)]: a SIMD's two waves are never both in a read segment or
+                // both in an MFMA segment, and nobody pads its shorter segment to the partner's longer one — the
+                // interval lasts read + mma of ONE wave instead of 2 x max(read, mma).  Per iteration k (phase k):
+                //   group 0:  reads(k), store | wait group(k+1) | BARRIER | issue group(k+3) | lgkmcnt(0) | mma(k)
+                //   group 1:  issue group(k+3) | reads(k), store | lgkmcnt(0) | mma(k) | wait group(k+2) | BARRIER
+                // (group(j) = the LDS-DMA pieces of phase j: W, X0 of a step for even j, X1 for odd j).
+                // RAW: group(j) is first read by group 0 after barrier j-1; group 0 waits for it before that barrier (in
+                // iteration j-1), group 1 before the same barrier (after mma(j-2)).  WAR: the slabs of phase j are last
+                // read by group 1 between barriers j and j+1 (reads retired before its mma); group(j+4) overwrites them
+                // and is issued by both groups right after barrier j+1.
+                // ---------------------------------------------------------------------------------------------------
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int I = 2 * kk + h;                         // deferred-epilogue step of this iteration
+                    const int nst = I >= 2 ? 2 : I;                   // epilogue stores younger than the awaited DMA group
+                    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+                    if (g == 1 && ABL != 4) { if (h == 0) { if (more1) Q_ISSUE_B(b ^ 1) } else { if (more2) Q_ISSUE_A(b) } }
+                    Q_EPI_BIAS(I, bias4)
+                    if (h == 0) { Q_RDW(b) Q_RDX(b, Q_X0) } else { Q_RDX(b, Q_X1) }
+                    if (I == 0) { if (pend) Q_EPI_STORE(23, rpend) pend = false; }
+                    else if (tr) Q_EPI_STORE(I - 1, rpend)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 0) {
+                        // group(k+1) landed; younger: group(k+2) (issued one iteration ago) and two stores
+                        if (h == 0) {       // X1(s) awaited; younger A(s+1) 5 (+ bias)
+                            if (!more1) q_wait_vm(0);
+                            else if (BIAS && kk == 11 && lastblk) { if (tr) q_wait_vm(6 + nst); else q_wait_vm(6); }
+                            else { if (tr) q_wait_vm(5 + nst); else q_wait_vm(5); }
+                        } else {            // A(s+1) awaited; younger X1(s+1) 2
+                            if (!more1) q_wait_vm(0);
+                            else { if (tr) q_wait_vm(2 + nst); else q_wait_vm(2); }
+                        }
+                        __builtin_amdgcn_s_barrier();
+                        if (ABL != 4) { if (h == 0) { if (more1) Q_ISSUE_B(b ^ 1) } else { if (more2) Q_ISSUE_A(b) } }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    Q_MMA(h, Q_EPI_COMPUTE(I, bias4, rpend), )
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 1) {
+                        // group(k+2) landed; younger: group(k+3) (issued at the top of this iteration) and two stores
+                        if (h == 0) {       // A(s+1) awaited; younger X1(s+1) 2
+                            if (!more1) q_wait_vm(0);
+                            else { if (tr) q_wait_vm(2 + nst); else q_wait_vm(2); }
+                        } else {            // X1(s+1) awaited; younger A(s+2) 5 (+ bias)
+                            if (!more2) q_wait_vm(0);
+                            else if (BIAS && kk == 10 && lastblk) { if (tr) q_wait_vm(6 + nst); else q_wait_vm(6); }
+                            else { if (tr) q_wait_vm(5 + nst); else q_wait_vm(5); }
+                        }
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+              }
             }
             pend = tr;
         }
@@ -342,7 +379,6 @@ void gemm_q192_kernel(GemmParams p) {
     // image in the now idle operand LDS — one [128 rows][384 B] slab per group — and write it out as full 384-byte
     // rows, 16 bytes per lane (8 rows = 3 KiB = three instructions).
     if (pend) { Q_EPI_STORE(23, rpend) pend = false; }
-    if (SCH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unconditional prefetches of the last two steps
     __syncthreads();                                              // every wave is done reading operand slabs
     char* const slab = smem + g * 49152;
 #pragma unroll
@@ -388,6 +424,8 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<2, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<4, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<5, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         attr_set = true;
     }
@@ -396,6 +434,8 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
     else if (ablation == 3) hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else if (ablation == 4) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else if (ablation == 5) hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else if (ablation == 6) hipLaunchKernelGGL((gemm_q192_kernel<4, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else if (ablation == 7) hipLaunchKernelGGL((gemm_q192_kernel<5, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
 }
 

@@ -43,7 +43,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="tiles per step per GPU (BASELINE config 2: 16)")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per step per GPU (default: the workload's BASELINE batch)")
+    ap.add_argument("--workload", default="encdec", choices=["encdec", "full", "vith256"],
+                    help="encdec: BASELINE configs[1] (headline: ViT-B 512^2 B=16, encoder + map_decoder); "
+                         "full: configs[2] (the same + sampler + TopoNet, 256 points per tile = SAMRoad.forward); "
+                         "vith256: configs[4] (toponet_vith_256.yaml, ViT-H 256^2 tiles, B=8, encoder + map_decoder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="tuning aid: skip the finite-output check (kernel ablations)")
@@ -66,8 +70,15 @@ def main():
     from sam_road_amd import _lib
     from sam_road_amd.distributed import broadcast_state_dict
 
-    cfg = Config(SAM_VERSION="vit_b", PATCH_SIZE=512, TOPONET_VERSION="normal", SAM_CKPT_PATH="",
-                 NO_SAM=False, USE_SAM_DECODER=False, ENCODER_LORA=False)
+    WL = {"encdec": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE, yaml="toponet_vitb_512_cityscale.yaml",
+                         what="ViT-B encoder + map_decoder (BASELINE configs[1])"),
+          "full": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE + 2.8, yaml="toponet_vitb_512_cityscale.yaml",
+                       what="full SAMRoad.forward: encoder + map_decoder + sampler + TopoNet on 256 points / tile (BASELINE configs[2])"),
+          "vith256": dict(version="vit_h", patch=256, batch=8, gflop=332.23 + 0.21, yaml="toponet_vith_256.yaml",
+                          what="ViT-H encoder + map_decoder (BASELINE configs[4])")}[args.workload]
+    P = WL["patch"]
+    cfg = Config(SAM_VERSION=WL["version"], PATCH_SIZE=P, TOPONET_VERSION="normal", SAM_CKPT_PATH="",
+                 NO_SAM=False, USE_SAM_DECODER=False, ENCODER_LORA=False, NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16)
     net = SAMRoad(cfg)
     # seeded random-init weights of the named architecture (no checkpoint exists offline)
     g = torch.Generator().manual_seed(1234)
@@ -86,9 +97,26 @@ def main():
     net.load_state_dict(sd, strict=True)
     net.eval().to(dev)
 
-    B = args.batch
+    B = args.batch or WL["batch"]
     gi = torch.Generator().manual_seed(100 + rank)
-    rgb = (torch.rand((B, 512, 512, 3), generator=gi) * 255).round().to(dev)
+    rgb = (torch.rand((B, P, P, 3), generator=gi) * 255).round().to(dev)
+    step = lambda: net.infer_masks_and_img_features(rgb)
+    if args.workload == "full":
+        # 256 synthetic graph points per tile (integer pixels, >= 16 px apart like NMS output), pairs by the pass-2 query
+        # builder (kNN 16 within 64 px, inferencer.py:148-176)
+        import numpy as np
+        from sam_road_amd.inferencer import build_patch_queries, _collate
+        rng = np.random.default_rng(7 + rank)
+        qs = []
+        for _ in range(B):
+            cand = rng.integers(0, P // 16, size=(4096, 2))
+            _, first = np.unique(cand[:, 0] * 64 + cand[:, 1], return_index=True)
+            pts = (cand[np.sort(first)][:256] * 16 + rng.integers(0, 4, size=(256, 2))).astype(np.int64)
+            qs.append(build_patch_queries(pts, 0, 0, P, P, cfg))
+        pts_t = torch.as_tensor(_collate([q[1] for q in qs])).to(dev)
+        pairs_t = torch.as_tensor(_collate([q[2] for q in qs])).to(dev)
+        valid_t = torch.as_tensor(_collate([q[3] for q in qs])).to(dev)
+        step = lambda: net(rgb, pts_t, pairs_t, valid_t)[1::2]
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -97,11 +125,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        net.infer_masks_and_img_features(rgb)
+        step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        scores, emb = net.infer_masks_and_img_features(rgb)
+        scores, emb = step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -112,23 +140,23 @@ def main():
     tiles_per_s = world * B * args.steps / elapsed
 
     out = {
-        "metric": "tiles/sec (512x512 ViT-B, SAMRoad.infer_masks_and_img_features: encoder + mask decoder)",
+        "metric": "tiles/sec (512x512 ViT-B, SAMRoad.infer_masks_and_img_features: encoder + mask decoder)" if args.workload == "encdec"
+                  else f"tiles/sec ({P}x{P} {WL['version']}, {WL['what']})",
         "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "toponet_vitb_512_cityscale.yaml, batch=16 512x512 tiles per GPU, ViT-B encoder "
-                               "+ map_decoder (BASELINE configs[1])",
-                   "tiles_per_step_per_gpu": B, "patch": 512, "input": "f32 NHWC resident in HBM",
+        "config": {"workload": f"{WL['yaml']}, batch={B} {P}x{P} tiles per GPU, {WL['what']}",
+                   "tiles_per_step_per_gpu": B, "patch": P, "input": "f32 NHWC resident in HBM",
                    "weights": "seeded random init", "parallelism": f"tile-dp{world}",
-                   "gflop_per_tile_algorithmic": GFLOP_PER_TILE,
-                   "whole_path_mfma_frac": round(tiles_per_s / world * GFLOP_PER_TILE / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+                   "gflop_per_tile_algorithmic": WL["gflop"],
+                   "whole_path_mfma_frac": round(tiles_per_s / world * WL["gflop"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
     }
 
     if rank == 0 and not args.no_roofline:
         ctx = _lib.Context.get(local_rank)
         ctx.profile_enable(True)
         for _ in range(max(1, min(args.steps, 5))):
-            net.infer_masks_and_img_features(rgb)
+            step()
         rows = ctx.profile_read()
         ctx.profile_enable(False)
         gemm = [r for r in rows if r["name"].startswith("gemm_")]
@@ -162,6 +190,7 @@ def main():
         oracle = SAMRoadOracle(AttrDict(cfg)).eval()
         oracle.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
         x = rgb[:2].cpu()
+        assert args.workload == "encdec", "the CPU baseline leg is defined for the headline workload (use --no-cpu-baseline)"
         oracle.infer_masks_and_img_features(x)
         t0 = time.perf_counter()
         iters = 3

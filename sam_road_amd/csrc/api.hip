@@ -215,7 +215,7 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
     const int D = cfg->embed_dim, heads = cfg->num_heads;
     if (D <= 0 || heads <= 0 || D % heads) return fail(c, SRH_ERR_BAD_ARG, "bad embed_dim / num_heads");
     const int hd = D / heads;
-    if (hd % 8 || hd > 96) return fail(c, SRH_ERR_UNSUPPORTED, "head_dim must be a multiple of 8 and <= 96");   // 64: MFMA kernels, 80 (ViT-H): generic kernel
+    if (hd != 64 && hd != 80) return fail(c, SRH_ERR_UNSUPPORTED, "head_dim must be 64 (MFMA attention kernels) or 80 (ViT-H: generic kernel)");
     if (cfg->patch_size % 16) return fail(c, SRH_ERR_BAD_ARG, "PATCH_SIZE must be a multiple of 16");
     const int S = cfg->patch_size / 16;
     if (S != 16 && S != 32 && S != 64) return fail(c, SRH_ERR_UNSUPPORTED, "PATCH_SIZE must be 256, 512 or 1024");

@@ -508,14 +508,16 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
 // queries are skipped, the rel-pos bias comes from the unscaled q and the tables.
 // grid = (image, head, window, block of 256 real queries).
 // ---------------------------------------------------------------------------------------------
-constexpr int GEN_HD = 96, GEN_KC = 128;
+constexpr int GEN_KC = 128;
+template <int NCH>      // head dim / 8 (compile time: 10 for ViT-H's 80, 8 for 64)
 __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
+    constexpr int hd = NCH * 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int hd = p.hd, win = p.win, S = p.S, nw = (S + win - 1) / win, D = p.heads * hd;
+    const int win = p.win, S = p.S, nw = (S + win - 1) / win, D = p.heads * hd;
     const int KC = win > 32 ? GEN_KC / 2 : GEN_KC;                    // keys per LDS chunk (the rel table grows with win)
-    f16* k_lds = reinterpret_cast<f16*>(smem);                       // [KC][hd]
-    f16* v_lds = k_lds + KC * hd;                                    // [KC][hd]
-    float* rel_lds = reinterpret_cast<float*>(v_lds + KC * hd);      // [256][2 * win]
+    f16* k_lds = reinterpret_cast<f16*>(smem);                        // [KC][hd] fp16 (consumed by v_dot2_f32_f16)
+    float* v_lds = reinterpret_cast<float*>(k_lds + KC * hd);         // [KC][hd] f32 (converted once, at staging)
+    float* rel_lds = v_lds + KC * hd;                                 // [256][2 * win]
     const int tid = threadIdx.x;
     const int nqb = (win * win + 255) / 256;
     int u = blockIdx.x;
@@ -530,17 +532,32 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     const bool active = qi < nreal;
     const int ry = active ? qi / nrx : 0, rx = active ? qi % nrx : 0;
     const size_t tok = ((size_t)b * S + wy * win + ry) * S + wx * win + rx;
-    float q[GEN_HD], o[GEN_HD];
+    f16x2 q2[NCH * 4];                                                // the query as fp16 pairs (exactly what the MFMA path multiplies)
+    float o[hd];
 #pragma unroll
-    for (int d = 0; d < GEN_HD; ++d) { q[d] = (active && d < hd) ? (float)p.qkv[tok * p.ld + head * hd + d] : 0.f; o[d] = 0.f; }
-    // rel-pos bias of this query: rel[k] = q . T[qc - k + win - 1]
+    for (int c = 0; c < NCH; ++c) {
+        f16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) t = *reinterpret_cast<const f16x8*>(p.qkv + tok * p.ld + head * hd + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q2[c * 4 + e] = f16x2{t[2 * e], t[2 * e + 1]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[c * 8 + e] = 0.f;
+    }
+    // rel-pos bias of this query: rel[k] = q . T[qc - k + win - 1]   (fp16 products, f32 accumulation)
     float* rel = rel_lds + tid * 2 * win;
     for (int k = 0; k < win; ++k) {
         const f16* th = p.table_h + (size_t)(ry - k + win - 1) * hd;
         const f16* tw = p.table_w + (size_t)(rx - k + win - 1) * hd;
         float ah = 0.f, aw = 0.f;
 #pragma unroll
-        for (int d = 0; d < GEN_HD; ++d) if (d < hd) { ah += q[d] * (float)th[d]; aw += q[d] * (float)tw[d]; }
+        for (int c = 0; c < NCH; ++c) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(th + c * 8), w8 = *reinterpret_cast<const f16x8*>(tw + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ah = __builtin_amdgcn_fdot2(q2[c * 4 + e], f16x2{a[2 * e], a[2 * e + 1]}, ah, false);
+                aw = __builtin_amdgcn_fdot2(q2[c * 4 + e], f16x2{w8[2 * e], w8[2 * e + 1]}, aw, false);
+            }
+        }
         rel[k] = ah; rel[win + k] = aw;
     }
     float m = -INFINITY, l = 0.f;
@@ -548,33 +565,54 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     for (int k0 = 0; k0 < nkeys; k0 += KC) {
         const int kc = min(KC, nkeys - k0);
         __syncthreads();
-        for (int it = tid; it < kc * (hd / 8); it += 256) {          // stage K / V chunk, 16 bytes per item
-            const int c = it % (hd / 8), kk = k0 + it / (hd / 8);
+        for (int it = tid; it < kc * NCH; it += 256) {                // stage K (fp16) / V (f32) chunk, 8 dims per item
+            const int c = it % NCH, kl = it / NCH, kk = k0 + kl;
             const int y = wy * win + kk / win, x = wx * win + kk % win;
             const bool real = y < S && x < S;
             const f16* src = real ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + head * hd : p.bias_qkv + head * hd;
-            *reinterpret_cast<uint4*>(k_lds + (it / (hd / 8)) * hd + c * 8) = *reinterpret_cast<const uint4*>(src + D + c * 8);
-            *reinterpret_cast<uint4*>(v_lds + (it / (hd / 8)) * hd + c * 8) = *reinterpret_cast<const uint4*>(src + 2 * D + c * 8);
+            *reinterpret_cast<uint4*>(k_lds + kl * hd + c * 8) = *reinterpret_cast<const uint4*>(src + D + c * 8);
+            const f16x8 v8 = *reinterpret_cast<const f16x8*>(src + 2 * D + c * 8);
+            *reinterpret_cast<f32x4*>(v_lds + kl * hd + c * 8) = f32x4{(float)v8[0], (float)v8[1], (float)v8[2], (float)v8[3]};
+            *reinterpret_cast<f32x4*>(v_lds + kl * hd + c * 8 + 4) = f32x4{(float)v8[4], (float)v8[5], (float)v8[6], (float)v8[7]};
         }
         __syncthreads();
         if (!active) continue;
-        for (int j = 0; j < kc; ++j) {
+        for (int j = 0; j < kc; ++j) {                                // every thread reads the same key row: LDS broadcast
             const int kk = k0 + j;
             float sdot = 0.f;
 #pragma unroll
-            for (int d = 0; d < GEN_HD; ++d) if (d < hd) sdot += q[d] * (float)k_lds[j * hd + d];
-            const float sc = sdot * p.scale + rel[kk / win] + rel[win + kk % win];
-            const float m_new = fmaxf(m, sc);
-            const float alpha = __expf(m - m_new), pe = __expf(sc - m_new);
-            l = l * alpha + pe;
+            for (int c = 0; c < NCH; ++c) {
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(k_lds + j * hd + c * 8);
 #pragma unroll
-            for (int d = 0; d < GEN_HD; ++d) if (d < hd) o[d] = o[d] * alpha + pe * (float)v_lds[j * hd + d];
-            m = m_new;
+                for (int e = 0; e < 4; ++e) sdot = __builtin_amdgcn_fdot2(q2[c * 4 + e], f16x2{kv[2 * e], kv[2 * e + 1]}, sdot, false);
+            }
+            const float sc = sdot * p.scale + rel[kk / win] + rel[win + kk % win];
+            if (sc > m) {                                             // rare after the first keys: rescale the running state
+                const float alpha = __expf(m - sc);
+                l *= alpha;
+#pragma unroll
+                for (int d = 0; d < hd; ++d) o[d] *= alpha;
+                m = sc;
+            }
+            const float pe = __expf(sc - m);
+            l += pe;
+#pragma unroll
+            for (int c = 0; c < NCH * 2; ++c) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(v_lds + j * hd + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[c * 4 + e] = fmaf(pe, vv[e], o[c * 4 + e]);
+            }
         }
     }
     if (!active) return;
     const float inv = 1.0f / l;
-    for (int d = 0; d < hd; ++d) p.out[tok * p.ldo + head * hd + d] = (f16)(o[d] * inv);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        f16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (f16)(o[c * 8 + e] * inv);
+        *reinterpret_cast<f16x8*>(p.out + tok * p.ldo + head * hd + c * 8) = t;
+    }
 }
 
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
@@ -583,16 +621,19 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     if (!p.ablate) p.ablate = env_abl;
     const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32)));
     if (!mfma_path) {      // other head dims (ViT-H) and the 64x64 global window of 1024-pixel tiles
-        if (p.hd > GEN_HD || p.hd % 8 || !p.table_h || !p.table_w || p.win > 64) return -2;
+        if ((p.hd != 64 && p.hd != 80) || !p.table_h || !p.table_w || p.win > 64) return -2;
         const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
-        const int lds = 2 * (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 2 + 256 * 2 * p.win * 4;
+        const int lds = (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 6 + 256 * 2 * p.win * 4;
         if (lds > 160 * 1024) return -2;
         static bool gattr = false;
         if (!gattr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             gattr = true;
         }
-        hipLaunchKernelGGL(attn_generic_kernel, dim3(p.B * nw * nw * p.heads * nqb), dim3(256), lds, s, p);
+        const dim3 grid(p.B * nw * nw * p.heads * nqb);
+        if (p.hd == 64) hipLaunchKernelGGL(attn_generic_kernel<8>, grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(attn_generic_kernel<10>, grid, dim3(256), lds, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     if (p.win == p.S) {

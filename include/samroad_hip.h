@@ -145,6 +145,17 @@ int srh_profile_read(srh_ctx* ctx, srh_profile_row* rows, int max_rows, int* n_r
  * reference's KDTree loop. */
 int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int32_t radius, uint8_t* kept);
 
+/* Pass-2 query builder for all tiles of a scene (reference inferencer.py:148-176: per-tile rtree box query + scipy
+ * KDTree.query(k = K+1, distance_upper_bound = R)).  pts int64 [n,2] (x,y) graph points; boxes int32 [n_tiles,4]
+ * (x0,y0,x1,y1), closed.  srh_pass2_count writes the number of points per tile; the caller builds
+ * offsets = exclusive prefix sum and allocates ids [total] and knn [total,K]; srh_pass2_fill writes, per tile, the point
+ * ids in ascending order and each point's K nearest other points of the tile (distance strictly < radius, ascending by
+ * (distance, index); -1 = missing).  ambiguous [total]: 1 for a source point whose scipy result is not determined by
+ * distances alone (tie at the cutoff, coincident points): the caller must recompute those points with scipy. */
+int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int64_t* counts);
+int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
+                   const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ SYMBOLS = {
     "srh_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "srh_op_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "srh_nms_points_host": (_I, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "srh_pass2_count": (_I, [_P, C.c_int64, _P, C.c_int32, _P]),
+    "srh_pass2_fill": (_I, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32]),
     "srh_profile_enable": (_I, [_P, _I]),
     "srh_profile_read": (_I, [_P, C.POINTER(ProfileRow), _I, C.POINTER(_I)]),
 }

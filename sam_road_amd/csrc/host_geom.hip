@@ -63,3 +63,88 @@ extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int6
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pass-2 query builder for ALL tiles of a scene in one call (reference inferencer.py:148-176, executed per tile from
+// Python there: rtree box query + scipy KDTree.query(k = K+1, distance_upper_bound = R)).  For every tile: the points
+// inside the CLOSED box [x0,x1] x [y0,y1] in ascending point index (= the reference's order after its rtree query +
+// sort), and for each of them its K nearest OTHER points of the same tile with distance STRICTLY below R (scipy's
+// distance_upper_bound is exclusive), ascending by (distance, tile-local index); missing neighbours are -1.
+// The neighbour SET is what the reference computes whenever it is unique.  It is not unique when the (K+1)-th and the
+// (K+2)-th candidate are equidistant (scipy keeps whichever its heap met first) or when another point coincides with the
+// source (scipy may then return the source itself as a neighbour): such source points are flagged in `ambiguous` and the
+// caller re-runs exactly the reference's scipy query for them (on a kd-tree of their tile's points).  Order INSIDE a set of equidistant neighbours is scipy-internal;
+// nothing downstream depends on it (TopoNet has no positional encoding along the neighbour axis and the edge votes are
+// keyed by (source, target)).
+// Two-step protocol: srh_pass2_count -> caller allocates -> srh_pass2_fill.  Tiles are processed by worker threads.
+// ---------------------------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <thread>
+
+extern "C" int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int64_t* counts) {
+    if (n < 0 || n_tiles < 0 || (n > 0 && !pts) || (n_tiles > 0 && (!boxes || !counts))) return SRH_ERR_BAD_ARG;
+    for (int32_t t = 0; t < n_tiles; ++t) {
+        const int64_t x0 = boxes[4 * t], y0 = boxes[4 * t + 1], x1 = boxes[4 * t + 2], y1 = boxes[4 * t + 3];
+        int64_t c = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t x = pts[2 * i], y = pts[2 * i + 1];
+            c += (x >= x0 && x <= x1 && y >= y0 && y <= y1);
+        }
+        counts[t] = c;
+    }
+    return 0;
+}
+
+// offsets[t] = sum(counts[:t]) (caller);  ids [total];  knn [total, K] tile-local neighbour index or -1;
+// ambiguous [total]: per source point (1 = recompute this point with the reference's scipy call on its tile)
+extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
+                              const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads) {
+    if (n < 0 || n_tiles < 0 || K <= 0 || radius < 0 || (n_tiles > 0 && (!boxes || !offsets || !ids || !knn || !ambiguous)))
+        return SRH_ERR_BAD_ARG;
+    const int64_t r2 = radius * radius;
+    auto work = [&](int32_t t_begin, int32_t t_end) {
+        std::vector<int64_t> lx, ly;
+        std::vector<std::pair<int64_t, int32_t>> cand;
+        for (int32_t t = t_begin; t < t_end; ++t) {
+            const int64_t x0 = boxes[4 * t], y0 = boxes[4 * t + 1], x1 = boxes[4 * t + 2], y1 = boxes[4 * t + 3];
+            int64_t* tid = ids + offsets[t];
+            int32_t* tk = knn + offsets[t] * K;
+            lx.clear(); ly.clear();
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t x = pts[2 * i], y = pts[2 * i + 1];
+                if (x >= x0 && x <= x1 && y >= y0 && y <= y1) { tid[lx.size()] = i; lx.push_back(x); ly.push_back(y); }
+            }
+            const int32_t m = (int32_t)lx.size();
+            uint8_t* tamb = ambiguous + offsets[t];
+            for (int32_t i = 0; i < m; ++i) {
+                bool amb = false;
+                cand.clear();
+                for (int32_t j = 0; j < m; ++j) {
+                    if (j == i) continue;
+                    const int64_t dx = lx[j] - lx[i], dy = ly[j] - ly[i], d2 = dx * dx + dy * dy;
+                    if (d2 < r2) cand.emplace_back(d2, j);
+                }
+                const size_t keep = std::min<size_t>((size_t)K, cand.size());
+                if (cand.size() > (size_t)K) {
+                    std::partial_sort(cand.begin(), cand.begin() + K + 1, cand.end());
+                    amb |= cand[K].first == cand[K - 1].first;          // cutoff falls inside a group of equidistant points
+                } else {
+                    std::sort(cand.begin(), cand.end());
+                }
+                amb |= !cand.empty() && cand[0].first == 0;             // a point coinciding with the source
+                for (size_t q = 0; q < (size_t)K; ++q) tk[(size_t)i * K + q] = q < keep ? cand[q].second : -1;
+                tamb[i] = amb ? 1 : 0;
+            }
+        }
+    };
+    const int32_t nt = std::max<int32_t>(1, std::min<int32_t>(n_threads, n_tiles));
+    if (nt == 1) { work(0, n_tiles); return 0; }
+    std::vector<std::thread> pool;
+    const int32_t per = (n_tiles + nt - 1) / nt;
+    for (int32_t w = 0; w < nt; ++w) {
+        const int32_t b = w * per, e = std::min(n_tiles, b + per);
+        if (b < e) pool.emplace_back(work, b, e);
+    }
+    for (auto& th : pool) th.join();
+    return 0;
+}

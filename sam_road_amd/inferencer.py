@@ -40,6 +40,58 @@ def build_patch_queries(graph_points, x0, y0, x1, y1, config):
     return ids, pts, np.stack([src, tgt], -1), valid
 
 
+def build_all_patch_queries(graph_points, infos, lo, hi, config):
+    """build_patch_queries for tiles [lo, hi) in ONE call into the library's host code (srh_pass2_count / srh_pass2_fill,
+    csrc/host_geom.hip: closed-box filter + exact integer kNN per tile, worker threads).  Tiles whose scipy result is not
+    determined by distances alone (tie at the k-th neighbour, coincident points) are recomputed with the reference's own
+    scipy call, so the neighbour SETS always equal the reference's; the order inside a group of equidistant neighbours
+    is scipy-internal and nothing downstream depends on it."""
+    import ctypes as C
+    import os
+    from . import _lib
+    k, r = int(config.MAX_NEIGHBOR_QUERIES), config.NEIGHBOR_RADIUS
+    n_tiles = hi - lo
+    if n_tiles <= 0:
+        return []
+    if float(r) != int(r) or not np.issubdtype(graph_points.dtype, np.integer):
+        return [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
+    lib = _lib.load()
+    pts = np.ascontiguousarray(graph_points, dtype=np.int64)
+    boxes = np.ascontiguousarray([[*infos[t][1], *infos[t][2]] for t in range(lo, hi)], dtype=np.int32)
+    counts = np.zeros(n_tiles, dtype=np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if lib.srh_pass2_count(vp(pts), pts.shape[0], vp(boxes), n_tiles, vp(counts)) != 0:
+        raise _lib.SrhError("srh_pass2_count failed")
+    offsets = np.zeros(n_tiles + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    ids = np.zeros(total, dtype=np.int64)
+    knn = np.zeros((total, k), dtype=np.int32)
+    amb = np.zeros(total, dtype=np.uint8)
+    if lib.srh_pass2_fill(vp(pts), pts.shape[0], vp(boxes), n_tiles, k, int(r), vp(offsets), vp(ids), vp(knn), vp(amb),
+                          max(1, min(16, (os.cpu_count() or 2) - 1))) != 0:
+        raise _lib.SrhError("srh_pass2_fill failed")
+    tile_of = np.repeat(np.arange(n_tiles), counts)
+    src_local = np.arange(total, dtype=np.int64) - offsets[:-1][tile_of]
+    valid = knn >= 0
+    pairs = np.stack([np.broadcast_to(src_local[:, None], (total, k)), np.where(valid, knn, src_local[:, None])], axis=-1)
+    local = pts[ids] - boxes[tile_of, :2].astype(np.int64)
+    cut = offsets[1:-1]
+    # ambiguous source points: the reference's own scipy query, on a kd-tree of their tile's points (rows overwritten in place)
+    amb_rows = np.nonzero(amb)[0]
+    if amb_rows.size:
+        for t in np.unique(tile_of[amb_rows]):
+            a, b_ = int(offsets[t]), int(offsets[t + 1])
+            rows = amb_rows[(amb_rows >= a) & (amb_rows < b_)]
+            tree = scipy.spatial.cKDTree(local[a:b_])
+            _, nn = tree.query(local[rows], k=k + 1, distance_upper_bound=r)
+            nn = nn[:, 1:]
+            ok = nn < (b_ - a)
+            valid[rows] = ok
+            pairs[rows, :, 1] = np.where(ok, nn, (rows - a)[:, None])
+    return list(zip(np.split(ids, cut), np.split(local, cut), np.split(pairs, cut), np.split(valid, cut)))
+
+
 def _collate(xs):
     """Zero-pad along axis 0 to the longest item and stack (graph_collate_fn-style padding, inferencer.py:179-185)."""
     length = max(x.shape[0] for x in xs)
@@ -69,14 +121,13 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
     float64 in the reference's order (tile, point, neighbour slot), so they are bit-identical to its dict loop."""
     bs = int(config.INFER_BATCH_SIZE)
     n_pts = graph_points.shape[0]
-    futs = [_pool().submit(build_patch_queries, graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
-    # launch every batch as soon as its queries exist (the GPU works on batch i while the host threads build the
-    # queries of the later batches); scores are fetched only after the last launch.  Indices travel as int32 and the
-    # integer pixel coordinates as float32 (exact; srh_toponet accepts both, model.py:47's division promotes anyway).
+    all_q = build_all_patch_queries(graph_points, infos, lo, hi, config)
+    # launch every batch before fetching any scores.  Indices travel as int32 and the integer pixel coordinates as float32
+    # (exact; srh_toponet accepts both, model.py:47's division promotes anyway).
     launched = []
     for off in range(lo, hi, bs):
         end = min(off + bs, hi)
-        qs = [f.result() for f in futs[off - lo:end - lo]]
+        qs = all_q[off - lo:end - lo]
         if max(q[1].shape[0] for q in qs) == 0:
             continue
         pts = _collate([q[1].astype(np.float32) for q in qs])

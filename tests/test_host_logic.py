@@ -82,6 +82,22 @@ def test_extract_graph_points_and_queries():
     assert (pairs[..., 0] == np.arange(len(ids))[:, None]).all()
     assert (valid[:, :-1] >= valid[:, 1:]).all()                      # valid is a prefix (App. D.5)
     assert (pairs[..., 1][~valid] == pairs[..., 0][~valid]).all()     # invalid target -> source
+    # the library's all-tiles builder: same ids / valid / neighbour SETS per source (order inside a group of equidistant
+    # neighbours is scipy-internal), scipy fallback for tiles whose k-th neighbour is tied
+    from sam_road_amd.inferencer import build_all_patch_queries
+    from sam_road_amd.tiling import get_patch_info_one_img
+    infos = get_patch_info_one_img(0, 256, 0, 128, 4)
+    allq = build_all_patch_queries(pts, infos, 0, len(infos), cfg)
+    assert len(allq) == len(infos)
+    for info, (a_ids, a_p, a_pairs, a_valid) in zip(infos, allq):
+        r_ids, r_p, r_pairs, r_valid = oscene.build_patch_queries(pts, info, AttrDict(cfg))
+        np.testing.assert_array_equal(a_ids, r_ids)
+        np.testing.assert_array_equal(a_p, r_p)
+        np.testing.assert_array_equal(a_valid, r_valid)
+        assert a_pairs.shape == r_pairs.shape and (a_pairs[..., 0] == r_pairs[..., 0]).all()
+        for i in range(len(a_ids)):
+            assert set(a_pairs[i, a_valid[i], 1].tolist()) == set(r_pairs[i, r_valid[i], 1].tolist())
+            assert (a_pairs[i, ~a_valid[i], 1] == i).all()
     # empty tile
     ids, p, pairs, valid = build_patch_queries(pts, 5000, 5000, 5100, 5100, cfg)
     assert p.shape == (0, 2) and pairs.shape == (0, 16, 2) and valid.shape == (0, 16)

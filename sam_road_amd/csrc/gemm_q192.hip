@@ -24,6 +24,7 @@
 // Epilogue stores share vmcnt with the DMA loads and may retire out of order with them: every counted wait uses
 // N = the number of younger LOADS only (safe for any store completion order), and each store is issued right
 // after a wait so that it has a full phase to be acknowledged before the next one.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -184,7 +185,7 @@ void gemm_q192_kernel(GemmParams p) {
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) { asm volatile("" : "+v"(wf[nt][0])); asm volatile("" : "+v"(wf[nt][1])); } \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(xf[mt][0])); asm volatile("" : "+v"(xf[mt][1])); } \
     if (ABL != 2) { \
-    __builtin_amdgcn_s_setprio(1); \
+    if (p.prio_mode == 0) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0); \
     DMA \
     EPI \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
@@ -193,7 +194,7 @@ void gemm_q192_kernel(GemmParams p) {
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][(h) * 4 + mt])); \
     asm volatile("" : "+v"(rpend)); \
-    __builtin_amdgcn_s_setprio(0); } }
+    if (p.prio_mode == 0) __builtin_amdgcn_s_setprio(0); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(1); } }
 #define Q_SEG_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     // deferred epilogue step I (0..23) of the finished tile: accumulator tile (nt = I % 3, j = I / 3)
 #define Q_EPI_BIAS(I, dst) { if (BIAS) dst = *reinterpret_cast<const f32x4*>( \
@@ -439,8 +440,11 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
     else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
 }
 
-int launch_gemm_q192(const GemmParams& p, hipStream_t stream, int ablation) {
-    if (!q192_supported(p)) return -2;
+int launch_gemm_q192(const GemmParams& p_in, hipStream_t stream, int ablation) {
+    if (!q192_supported(p_in)) return -2;
+    static const int env_prio = getenv("SRH_Q192_PRIO") ? atoi(getenv("SRH_Q192_PRIO")) : 0;
+    GemmParams p = p_in;
+    if (!p.prio_mode) p.prio_mode = env_prio;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0; hipDeviceProp_t prop;

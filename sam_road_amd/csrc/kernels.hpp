@@ -15,6 +15,7 @@ struct GemmParams {
     f16* out_f16 = nullptr; int ldc16 = 0;
     int act = 0;                               // 0 none, 1 exact-erf GELU, 2 ReLU (applied after bias)
     int conv_S = 0, conv_C = 0;                // >0: implicit 3x3 conv over [B,S,S,C]
+    int prio_mode = 0;                         // tuning aid (env SRH_Q192_PRIO): 0 s_setprio 1 around the MFMA segment, 1 none, 2 around the read segment
     unsigned long long* dbg = nullptr;         // tuning aid (gemm_q192 ablation 3): per-segment cycle sums
     int variant = 0;                           // 0 LDS-DMA 128x128 (default), 1 register-staged 128x128, 2 register-staged 256x256
 };
@@ -23,6 +24,7 @@ int launch_gemm(const GemmParams& p, hipStream_t s);
 bool q192_supported(const GemmParams& p);
 bool q192_preferred(const GemmParams& p);
 int launch_gemm_q192(const GemmParams& p, hipStream_t s, int ablation = 0);
+int launch_gemm_w192(const GemmParams& p, hipStream_t s, int ablation = 0);   // one-wave-per-SIMD variant (gemm_w192.hip)
 
 // Row LayerNorm (biased variance) f32 [M,D] -> fp16 and/or f32; gamma == nullptr => cast only.
 struct NormParams {

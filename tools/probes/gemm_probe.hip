@@ -17,11 +17,11 @@ using namespace srh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 __global__ void naive_gemm(const f16* A, const f16* W, const float* bias, const float* resid, int M, int N, int K, int act,
-                           float* out) {
+                           float* out, int lda, int ldw) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += (float)A[(size_t)m * K + k] * (float)W[(size_t)n * K + k];
+    for (int k = 0; k < K; ++k) s += (float)A[(size_t)m * lda + k] * (float)W[(size_t)n * ldw + k];
     s += bias[n];
     if (act == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));
     if (resid) s += resid[(size_t)m * N + n];
@@ -55,7 +55,9 @@ int main(int argc, char** argv) {
     std::normal_distribution<float> nd(0.f, 1.f);
     for (const Shape& s : all) {
         if (("," + which + ",").find(std::string(",") + s.name + ",") == std::string::npos) continue;
-        const size_t nA = (size_t)s.M * s.K, nW = (size_t)s.N * s.K, nO = (size_t)s.M * s.N;
+        const int pad = getenv("PROBE_LD_PAD") ? atoi(getenv("PROBE_LD_PAD")) : 0;      // extra elements per operand row
+        const int LDA = s.K + pad, LDW = s.K + pad;
+        const size_t nA = (size_t)s.M * LDA, nW = (size_t)s.N * LDW, nO = (size_t)s.M * s.N;
         std::vector<f16> hA(nA), hW(nW);
         std::vector<float> hb(s.N), hR(s.resid ? nO : 0);
         for (auto& v : hA) v = (f16)(0.5f * nd(rng));
@@ -70,11 +72,11 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(db, hb.data(), s.N * 4, hipMemcpyHostToDevice));
-        naive_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(dA, dW, db, dR, s.M, s.N, s.K, s.act, ref);
+        naive_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(dA, dW, db, dR, s.M, s.N, s.K, s.act, ref, LDA, LDW);
         CK(hipDeviceSynchronize());
         auto make = [&](int variant) {
             GemmParams g;
-            g.A = dA; g.lda = s.K; g.W = dW; g.ldw = s.K; g.M = s.M; g.N = s.N; g.K = s.K; g.bias = db;
+            g.A = dA; g.lda = LDA; g.W = dW; g.ldw = LDW; g.M = s.M; g.N = s.N; g.K = s.K; g.bias = db;
             g.resid = dR; g.ldr = s.N; g.act = s.act; g.variant = variant;
             if (s.f16out) { g.out_f16 = o16; g.ldc16 = s.N; } else { g.out_f32 = o32; g.ldc = s.N; }
             g.dbg = ddbg;

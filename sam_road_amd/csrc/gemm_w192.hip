@@ -48,7 +48,11 @@ __device__ __forceinline__ void w_tile_of(int vb, int ntiles, int tiles_m, int t
 // k-tile, so the k-tile after the next one is pulled into L2 instead: one 4-byte load per 128-byte operand line (112 lines
 // per wave per k-tile = two wave instructions, written to an LDS scratch so that no VGPR is involved), issued two k-tiles
 // ahead of the DMA that will then hit L2.
-template <int ABL, int ACT, bool BIAS, bool PF>   // ABL: 0 normal, 1 no epilogue stores, 2 no MFMA
+// SPREAD: the 14 DMA pieces of a k-tile are not issued as one burst after the barrier but trickled between the MFMAs of the
+// next four k-steps (7 + 4 + 3 + 0).  PMC showed the average L2 read latency is only ~350 clk and the TA busy 28 %, yet a
+// wave that issues a burst of buffer_load...lds stalls until the TA has taken every piece of EVERY wave (~20 clk each, 56
+// per k-tile): with a burst, all four waves — and with them the matrix pipes — sit idle for ~1000 clk per k-tile.
+template <int ABL, int ACT, bool BIAS, bool PF, bool SPREAD>   // ABL: 0 normal, 1 no epilogue stores, 2 no MFMA
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_w192_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,9 +83,9 @@ void gemm_w192_kernel(GemmParams p) {
 #define W_ISSUE(buf) { \
     const int sw_ = d_n0 * p.ldw * 2 + d_kt * 128, sx_ = d_m0 * p.lda * 2 + d_kt * 128; \
     _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_vptr)(smem + (buf) * W_BUF + (wave + 4 * i_) * 1024), 16, vW[i_], sw_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_vptr)(smem + (buf) * W_BUF + (wave + 4 * i_) * 1024), 16, vW[0], sw_ + i_ * 64 * p.ldw, 0, 0); \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(smem + (buf) * W_BUF + W_WBUF + (wave + 4 * i_) * 1024), 16, vX[i_], sx_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(smem + (buf) * W_BUF + W_WBUF + (wave + 4 * i_) * 1024), 16, vX[0], sx_ + i_ * 64 * p.lda, 0, 0); \
     ++d_step; \
     if (++d_kt == nk) { d_kt = 0; ++d_ti; if (d_step < S_total) w_tile_of(blockIdx.x + d_ti * G, ntiles, tiles_m, tiles_n, d_m0, d_n0); } }
     // warm L2 with the k-tile the DMA stream will issue NEXT (d_* already point at it)
@@ -104,6 +108,22 @@ void gemm_w192_kernel(GemmParams p) {
 #define W_MM(set) { if (ABL != 2) { \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) acc[i_][j_] = mfma32(fw[set][i_], fx[set][j_], acc[i_][j_]); } }
+    // one DMA piece (0..5: W rows, 6..13: X rows) of the k-tile described by (sp_w, sp_x) into buffer sp_buf
+    int sp_w = 0, sp_x = 0;
+#define W_PIECE(q, buf) { { \
+    /* piece i of a slab starts 32 rows below piece i-1 and the swizzle key has period 16 rows: one lane offset serves all */ \
+    if ((q) < 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_vptr)(smem + (buf) * W_BUF + (wave + 4 * (q)) * 1024), 16, vW[0], sp_w + (q) * 64 * p.ldw, 0, 0); \
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(smem + (buf) * W_BUF + W_WBUF + (wave + 4 * ((q) - 6)) * 1024), 16, vX[0], sp_x + ((q) - 6) * 64 * p.lda, 0, 0); } }
+    // 12 MFMAs of one k-step with DMA pieces q0 .. q0+n-1 woven in (one piece after every 12/n-th MFMA).  The MFMAs are
+    // volatile asm here: the builtin is a pure node the scheduler slides across the (side-effecting) DMA issues, and pinning
+    // its AGPR accumulators with empty asm makes the compiler bounce them through VGPRs.  Pieces are issued unconditionally
+    // (past the end of the work list they re-fetch the last k-tile into a retired buffer) so that a k-step stays one block.
+#define W_MM_DMA(set, q0, n, buf) { \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) { \
+        if (ABL != 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i_][j_]) : "v"(fw[set][i_]), "v"(fx[set][j_])); \
+        const int m_ = i_ * 4 + j_; \
+        if ((n) > 0 && (m_ + 1) * (n) / 12 > m_ * (n) / 12) { W_PIECE((q0) + m_ * (n) / 12, buf) } } }
 
     f32x16 acc[3][4];
 #pragma unroll
@@ -115,7 +135,14 @@ void gemm_w192_kernel(GemmParams p) {
 
     // prologue: k-tiles 0 and 1
     W_ISSUE(0)
-    if (S_total > 1) { W_ISSUE(1) if (PF && S_total > 2) { W_PREFETCH() asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+    if (SPREAD) {
+        // k-tile 1: pieces 0..6 now, 7..13 ride on k-tile 0's MFMAs like in the steady state
+        sp_w = d_n0 * p.ldw * 2 + d_kt * 128; sp_x = d_m0 * p.lda * 2 + d_kt * 128;
+        if (S_total > 1) { ++d_step; if (++d_kt == nk) { d_kt = 0; ++d_ti; if (d_step < S_total) w_tile_of(blockIdx.x + d_ti * G, ntiles, tiles_m, tiles_n, d_m0, d_n0); } }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) W_PIECE(q, 1)
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else if (S_total > 1) { W_ISSUE(1) if (PF && S_total > 2) { W_PREFETCH() asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     W_RD(0, 0, 0)
@@ -127,6 +154,7 @@ void gemm_w192_kernel(GemmParams p) {
         for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
             for (int b = 0; b < 2; ++b, --s_left) {        // k-tile kt + b lives in buffer b (nk is even)
+              if (!SPREAD) {
                 W_RD(1, b, 1)
                 W_MM(0)
                 W_RD(0, b, 2)
@@ -143,6 +171,33 @@ void gemm_w192_kernel(GemmParams p) {
                     if (s_left > 2) { W_ISSUE(b) if (PF) { if (s_left > 3) W_PREFETCH() else { W_PREFETCH() } } }
                 }
                 W_MM(1)
+              } else {
+                // pieces 7..13 of k-tile t+1 (target buffer b ^ 1) ride on k-step 0; k-steps 1 and 2 carry none, so the last piece
+                // has two and a half k-steps (~1000 clk) to land before the hand-over waits for it.  (Spreading further — 4 + 3
+                // pieces on k-steps 0 and 1 — leaves an L2 miss too little time: measured 25 % slower than the burst.)
+                W_RD(1, b, 1)
+                W_MM_DMA(0, 7, 7, b ^ 1)
+                W_RD(0, b, 2)
+                W_MM_DMA(1, 14, 0, b ^ 1)
+                W_RD(1, b, 3)
+                W_MM_DMA(0, 0, 0, b)
+                if (s_left > 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    W_RD(0, b ^ 1, 0)
+                    // start k-tile t+2 (into the buffer just retired): describe it, issue its first 7 pieces inside the last k-step
+                    if (s_left > 2) {
+                        sp_w = d_n0 * p.ldw * 2 + d_kt * 128; sp_x = d_m0 * p.lda * 2 + d_kt * 128;
+                        ++d_step;
+                        if (++d_kt == nk) { d_kt = 0; ++d_ti; if (d_step < S_total) w_tile_of(blockIdx.x + d_ti * G, ntiles, tiles_m, tiles_n, d_m0, d_n0); }
+                    }
+                    W_MM_DMA(1, 0, 7, b)
+                } else {
+                    W_MM_DMA(1, 0, 0, b)
+                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // asm MFMA results -> compiler-scheduled reads
+                }
+              }
             }
         }
         // tile done: epilogue straight from the accumulators (lane: row m = frow, 4 consecutive columns per register quad)
@@ -168,7 +223,7 @@ void gemm_w192_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));       // keep the MFMAs alive
+                for (int j = 0; j < 4; ++j) asm volatile("" :: "a"(acc[i][j]));       // keep the MFMAs alive
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -176,6 +231,7 @@ void gemm_w192_kernel(GemmParams p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (SPREAD) asm volatile("s_nop 7" ::: "memory");
         if (ti + 1 < my_tiles) w_tile_of(blockIdx.x + (ti + 1) * G, ntiles, tiles_m, tiles_n, c_m0, c_n0);
     }
 }
@@ -184,21 +240,27 @@ template <int ACT, bool BIAS>
 static void w192_launch(const GemmParams& p, hipStream_t stream, int grid, int ablation) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<0, ACT, BIAS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<1, ACT, BIAS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<2, ACT, BIAS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<0, ACT, BIAS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<1, ACT, BIAS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<2, ACT, BIAS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<0, ACT, BIAS, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<1, ACT, BIAS, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<2, ACT, BIAS, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<0, ACT, BIAS, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<1, ACT, BIAS, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<2, ACT, BIAS, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<0, ACT, BIAS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<1, ACT, BIAS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w192_kernel<2, ACT, BIAS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS + 2048);
         attr_set = true;
     }
     const int L = W_LDS + 2048;
-    if (ablation == 1) hipLaunchKernelGGL((gemm_w192_kernel<1, ACT, BIAS, false>), dim3(grid), dim3(256), L, stream, p);
-    else if (ablation == 2) hipLaunchKernelGGL((gemm_w192_kernel<2, ACT, BIAS, false>), dim3(grid), dim3(256), L, stream, p);
-    else if (ablation == 3) hipLaunchKernelGGL((gemm_w192_kernel<0, ACT, BIAS, true>), dim3(grid), dim3(256), L, stream, p);
-    else if (ablation == 4) hipLaunchKernelGGL((gemm_w192_kernel<1, ACT, BIAS, true>), dim3(grid), dim3(256), L, stream, p);
-    else if (ablation == 5) hipLaunchKernelGGL((gemm_w192_kernel<2, ACT, BIAS, true>), dim3(grid), dim3(256), L, stream, p);
-    else hipLaunchKernelGGL((gemm_w192_kernel<0, ACT, BIAS, false>), dim3(grid), dim3(256), L, stream, p);
+    if (ablation == 1) hipLaunchKernelGGL((gemm_w192_kernel<1, ACT, BIAS, false, false>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 2) hipLaunchKernelGGL((gemm_w192_kernel<2, ACT, BIAS, false, false>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 3) hipLaunchKernelGGL((gemm_w192_kernel<0, ACT, BIAS, true, false>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 4) hipLaunchKernelGGL((gemm_w192_kernel<1, ACT, BIAS, true, false>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 5) hipLaunchKernelGGL((gemm_w192_kernel<2, ACT, BIAS, true, false>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 6) hipLaunchKernelGGL((gemm_w192_kernel<0, ACT, BIAS, false, true>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 7) hipLaunchKernelGGL((gemm_w192_kernel<1, ACT, BIAS, false, true>), dim3(grid), dim3(256), L, stream, p);
+    else if (ablation == 8) hipLaunchKernelGGL((gemm_w192_kernel<2, ACT, BIAS, false, true>), dim3(grid), dim3(256), L, stream, p);
+    else hipLaunchKernelGGL((gemm_w192_kernel<0, ACT, BIAS, false, false>), dim3(grid), dim3(256), L, stream, p);
 }
 
 int launch_gemm_w192(const GemmParams& p, hipStream_t stream, int ablation) {

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsamroad_hip.so")
+# SRH_LIB_PATH: load another build of the same library (A/B measurements of kernel changes); still no CPU fallback
+LIB_PATH = os.environ.get("SRH_LIB_PATH") or os.path.join(_HERE, "libsamroad_hip.so")
 
 SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ int vt_slot(int i) {
 
 struct QState {
     f16x8 q[4];        // B fragments of the lane's query, 4 k-steps of 16
-    float relw[16];    // rel_w / scale at the lane's 16 keys of a tile (tile-invariant)
+    f32x16 relw;       // rel_w / scale at the lane's 16 keys of a tile (tile-invariant): the S^T MFMA chain's C operand
     float m, l;        // running max (raw units) and this half's partial row sum
     f32x16 o[2];       // O^T accumulators, d tiles 0..31 / 32..63
 };
@@ -58,22 +58,20 @@ __device__ __forceinline__ void read_kfrag(f16x8 (&kf)[4], const char* k_lds, in
 }
 
 // One 32-row key tile.  The V^T fragment reads are issued right after the S^T MFMAs and BEFORE the softmax
-// VALU block (order pinned with sched_barrier), so their LDS latency hides behind ~200 VALU instructions
+// VALU block (order pinned with sched_barrier), so their LDS latency hides behind ~150 VALU instructions
 // instead of stalling the P.V MFMAs — with only 2 waves per SIMD nothing else would cover it.
+// The kernel is VALU-ISSUE bound (PMC: the two waves of a SIMD keep its issue port ~85 % busy at ~10 VALU instructions per
+// score element, while dropping the exps or half the MFMAs changes nothing), so the tile is written for instruction count:
+// rel_w enters as the C operand of the first MFMA (no accumulator init), rel_h — one or two scalars per tile — is folded
+// into the row-max and into the addend of the exp argument's FMA, the row sum uses packed adds.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int WIN>
 __device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], const char* vt_lds,
                                           float rh0, float rh1, float c_exp, int lane) {
     const int half = lane >> 5, row = lane & 31;
-    f32x16 s;
+    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float rh = rh0;
-        if (WIN == 16) rh = r >= 8 ? rh1 : rh0;
-        if (WIN == 14) rh = (r >= 8 || (half == 1 && r >= 6)) ? rh1 : rh0;
-        s[r] = st.relw[r] + rh;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
+    for (int ks = 1; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
     f16x8 vf[2][2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -84,13 +82,30 @@ __device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], cons
             vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + d * 64 + c * 16);
         }
     __builtin_amdgcn_sched_barrier(0);
-    if (WIN == 14) {
+    // key rows of the lane's 16 scores: WIN 32: one window row per tile; WIN 16: r < 8 -> row 0, r >= 8 -> row 1;
+    // WIN 14: keys 0..13 / 14..27 -> r < 6 row 0, r = 6, 7 row `half`, r = 8..11 row 1, r >= 12: row 1 (half 0) / no key (half 1)
+    const float rhm = WIN == 14 ? (half ? rh1 : rh0) : rh0;        // rel_h of r = 6, 7
+    float mloc;
+    if (WIN == 32) {
+        mloc = s[0];
 #pragma unroll
-        for (int r = 12; r < 16; ++r) s[r] = half ? -INFINITY : s[r];   // rows 28..31 are not keys
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+        mloc += rh0;
+    } else if (WIN == 16) {
+        float ma = s[0], mb = s[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, s[r]); mb = fmaxf(mb, s[8 + r]); }
+        mloc = fmaxf(ma + rh0, mb + rh1);
+    } else {
+        float ma = s[0], mb = s[8];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) ma = fmaxf(ma, s[r]);
+#pragma unroll
+        for (int r = 9; r < 12; ++r) mb = fmaxf(mb, s[r]);
+        float mt = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
+        mb = fmaxf(mb, half ? -INFINITY : mt);                   // rows 28..31 are not keys
+        mloc = fmaxf(fmaxf(ma + rh0, mb + rh1), fmaxf(s[6], s[7]) + rhm);
     }
-    float mloc = s[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(st.m, mloc);
     // rescale the running state only when some lane's max moved (wave-uniform branch; after the first
@@ -105,15 +120,23 @@ __device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], cons
         st.m = m_new;
     }
     const float mc = -m_new * c_exp;
-    float sum = 0.f;
+    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = WIN == 32 ? mc0 : fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
+    const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;  // r >= 12: exp2(-inf) = 0 for the rows that are not keys
+    f32x2 sum2 = {0.f, 0.f};
     f16x8 pb[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c_exp, mc));   // raw v_exp_f32: exp2(-inf) = 0
-        sum += pv;
-        pb[r >> 3][r & 7] = (f16)pv;
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 pv;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int rr = r + e;
+            const float ad = WIN == 32 ? mc0 : WIN == 16 ? (rr >= 8 ? mc1 : mc0) : (rr < 6 ? mc0 : rr < 8 ? mcm : rr < 12 ? mc1 : mct);
+            pv[e] = __builtin_amdgcn_exp2f(fmaf(s[rr], c_exp, ad));   // raw v_exp_f32: exp2(-inf) = 0
+            pb[rr >> 3][rr & 7] = (f16)pv[e];
+        }
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(sum2) : "v"(pv));      // hipcc scalarises a plain f32x2 add here
     }
-    st.l += sum;
+    st.l += sum2[0] + sum2[1];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -459,14 +482,19 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     uint4 rk0, rk1, rv0, rv1, rv2, rv3;
     const int s_c = tid & 7, s_i = (tid >> 3) & 31;                 // K item: chunk, row (tile = e)
     const int s_dc = tid & 7, s_kq = (tid >> 3) & 7, s_tl = tid >> 6;  // V item (tid < 128)
-    const f16* kbase = p.qkv + (tok0 + s_i) * p.ld + D + head * HD + s_c * 8;
-    const f16* vbase = p.qkv + (tok0 + s_kq * 4) * p.ld + 2 * D + head * HD + s_dc * 8;
-#define SRH_LOAD_STAGE(sidx) { \
-        rk0 = *reinterpret_cast<const uint4*>(kbase + (size_t)((sidx) * 2 + 0) * 32 * p.ld); \
-        rk1 = *reinterpret_cast<const uint4*>(kbase + (size_t)((sidx) * 2 + 1) * 32 * p.ld); \
-        if (tid < 128) { const f16* vb_ = vbase + (size_t)((sidx) * 2 + s_tl) * 32 * p.ld; \
-            rv0 = *reinterpret_cast<const uint4*>(vb_); rv1 = *reinterpret_cast<const uint4*>(vb_ + p.ld); \
-            rv2 = *reinterpret_cast<const uint4*>(vb_ + 2 * p.ld); rv3 = *reinterpret_cast<const uint4*>(vb_ + 3 * p.ld); } }
+    // Staging loads as buffer loads: the per-thread offsets are loop-invariant VGPRs and the stage advances a scalar
+    // offset, so the key loop carries no address arithmetic on the (binding) VALU.  Offsets are relative to the image's
+    // first token: S*S*ld*2 bytes < 2^31 for every supported S.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qkv + tok0 * p.ld), 0, 0x7fffffff, 0x00020000);
+    const int ldb = p.ld * 2;
+    const int ko0 = s_i * ldb + (D + head * HD + s_c * 8) * 2, ko1 = ko0 + 32 * ldb;
+    const int vo0 = (s_tl * 32 + s_kq * 4) * ldb + (2 * D + head * HD + s_dc * 8) * 2;
+    const int vo1 = vo0 + ldb, vo2 = vo0 + 2 * ldb, vo3 = vo0 + 3 * ldb;
+#define SRH_LD128(dst, vo, so) { const u32x4 t_ = __builtin_amdgcn_raw_buffer_load_b128(rsq, vo, so, 0); dst = make_uint4(t_[0], t_[1], t_[2], t_[3]); }
+#define SRH_LOAD_STAGE(sidx) { const int so_ = (sidx) * 64 * ldb; \
+        SRH_LD128(rk0, ko0, so_) SRH_LD128(rk1, ko1, so_) \
+        if (tid < 128) { SRH_LD128(rv0, vo0, so_) SRH_LD128(rv1, vo1, so_) SRH_LD128(rv2, vo2, so_) SRH_LD128(rv3, vo3, so_) } }
 #define SRH_STORE_STAGE(buf) { char* base_ = smem + (buf) * STAGE; \
         *reinterpret_cast<uint4*>(base_ + s_i * 128 + swz8(s_i, s_c) * 16) = rk0; \
         *reinterpret_cast<uint4*>(base_ + 4096 + s_i * 128 + swz8(s_i, s_c) * 16) = rk1; \
@@ -477,25 +505,31 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     SRH_LOAD_STAGE(0)
     SRH_STORE_STAGE(0)
     __syncthreads();
-    for (int sidx = 0; sidx < NSTAGE; ++sidx) {
-        const int buf = sidx & 1;
-        const int snext = sidx + 1 < NSTAGE ? sidx + 1 : sidx;   // last stage re-loads itself (no branch)
-        if (p.ablate != 2) SRH_LOAD_STAGE(snext)
-        const char* base = smem + buf * STAGE;
-        if (p.ablate != 1) {
-            f16x8 kfA[4], kfB[4];
-            read_kfrag(kfA, base, lane);
-            read_kfrag(kfB, base + 4096, lane);
-            const int t0 = sidx * 2;
-            float rh0 = rh[(lane & 31) * (WP + 1) + t0 * RPT];
-            float rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + t0 * RPT + 1] : 0.f;
-            attn_tile<WIN>(st, kfA, base + 8192, rh0, rh1, c_exp, lane);
-            rh0 = rh[(lane & 31) * (WP + 1) + (t0 + 1) * RPT];
-            rh1 = RPT == 2 ? rh[(lane & 31) * (WP + 1) + (t0 + 1) * RPT + 1] : 0.f;
-            attn_tile<WIN>(st, kfB, base + 8192 + 4096, rh0, rh1, c_exp, lane);
-        }
-        if (p.ablate != 2) SRH_STORE_STAGE(buf ^ 1)
-        __syncthreads();
+    // two stages per trip so that the LDS buffer index is a compile-time constant: every ds_read / ds_write address is then
+    // a loop-invariant lane offset plus an immediate (no per-access address VALU in the issue-bound key loop)
+    static_assert(NSTAGE % 2 == 0, "the key loop is unrolled by two stages");
+    const float* rhp = rh + (lane & 31) * (WP + 1);
+#define SRH_STAGE(sidx, buf) { \
+        const int snext_ = (sidx) + 1 < NSTAGE ? (sidx) + 1 : (sidx);   /* last stage re-loads itself (no branch) */ \
+        if (p.ablate != 2 && p.ablate != 8) SRH_LOAD_STAGE(snext_) \
+        const char* base = smem + (buf) * STAGE; \
+        if (p.ablate != 1) { \
+            f16x8 kfA[4], kfB[4]; \
+            read_kfrag(kfA, base, lane); \
+            read_kfrag(kfB, base + 4096, lane); \
+            float rh0 = rhp[((buf) * 2) * RPT]; \
+            float rh1 = RPT == 2 ? rhp[((buf) * 2) * RPT + 1] : 0.f; \
+            attn_tile<WIN>(st, kfA, base + 8192, rh0, rh1, c_exp, lane); \
+            rh0 = rhp[((buf) * 2 + 1) * RPT]; \
+            rh1 = RPT == 2 ? rhp[((buf) * 2 + 1) * RPT + 1] : 0.f; \
+            attn_tile<WIN>(st, kfB, base + 8192 + 4096, rh0, rh1, c_exp, lane); \
+        } \
+        if (p.ablate != 2 && p.ablate != 8) SRH_STORE_STAGE((buf) ^ 1) \
+        if (p.ablate != 8) __syncthreads(); }
+    for (int sidx = 0; sidx < NSTAGE; sidx += 2) {
+        SRH_STAGE(sidx, 0)
+        SRH_STAGE(sidx + 1, 1)
+        rhp += 4 * RPT;
     }
     store_query(st, p, tok, head, lane, true);
 }

@@ -31,7 +31,7 @@ def build_patch_queries(graph_points, x0, y0, x1, y1, config):
     pts = graph_points[ids, :] - np.array([[x0, y0]], dtype=graph_points.dtype)
     if n == 0:
         return ids, pts.reshape(0, 2), np.zeros((0, k, 2), np.int64), np.zeros((0, k), bool)
-    tree = scipy.spatial.cKDTree(pts)
+    tree = scipy.spatial.KDTree(pts)          # the reference's class (inferencer.py:156): leafsize 10, which decides ties
     _, knn = tree.query(pts, k=k + 1, distance_upper_bound=config.NEIGHBOR_RADIUS)
     knn = knn[:, 1:]
     src = np.tile(np.arange(n)[:, None], (1, k))
@@ -83,7 +83,7 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config):
         for t in np.unique(tile_of[amb_rows]):
             a, b_ = int(offsets[t]), int(offsets[t + 1])
             rows = amb_rows[(amb_rows >= a) & (amb_rows < b_)]
-            tree = scipy.spatial.cKDTree(local[a:b_])
+            tree = scipy.spatial.KDTree(local[a:b_])        # same class and defaults as the reference (leafsize decides ties)
             _, nn = tree.query(local[rows], k=k + 1, distance_upper_bound=r)
             nn = nn[:, 1:]
             ok = nn < (b_ - a)

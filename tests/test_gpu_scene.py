@@ -87,8 +87,9 @@ def test_infer_one_img_end_to_end(pair):
     edges_r, sums_r, cnts_r = oscene.infer_pass2(oracle, feats, pts, infos, AttrDict(cfg))
     got = {(int(a), int(b)) for a, b in edges.tolist()}
     ref = {(int(a), int(b)) for a, b in edges_r.tolist()}
-    # every oracle edge decision with a margin > 0.01 from the threshold must be reproduced
-    firm = {e for e, s in sums_r.items() if abs(s / cnts_r[e] - cfg["TOPO_THRESHOLD"]) > 0.01}
+    # every oracle edge decision with a margin > 0.003 from the threshold must be reproduced (measured max |HIP - oracle| mean edge
+    # score over 12k edges: 6e-4, tools/scene_edge_diag.py)
+    firm = {e for e, s in sums_r.items() if abs(s / cnts_r[e] - cfg["TOPO_THRESHOLD"]) > 0.003}
     assert {e for e in ref if e in firm} == {e for e in got if e in firm}
     assert len(got ^ ref) <= max(2, 0.02 * len(ref))
     assert len(sums_r) > 50

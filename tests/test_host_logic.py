@@ -103,6 +103,35 @@ def test_extract_graph_points_and_queries():
     assert p.shape == (0, 2) and pairs.shape == (0, 16, 2) and valid.shape == (0, 16)
 
 
+def test_queries_with_tied_cutoff_match_reference_kdtree():
+    """Integer pixel coordinates make equidistant neighbours common; when the tie straddles the K-th slot the chosen
+    neighbour is decided by the kd-tree's shape, i.e. by the reference's `scipy.spatial.KDTree(pts)` defaults
+    (inferencer.py:156; leafsize 10 — cKDTree's default of 16 picks differently).  Lattice-like points: every source
+    has a tied cutoff."""
+    from oracle import scene as oscene
+    from oracle.samroad import AttrDict
+    from sam_road_amd.inferencer import build_all_patch_queries
+    from sam_road_amd.tiling import get_patch_info_one_img
+    cfg = Config(NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16)
+    rng = np.random.default_rng(3)
+    g = np.arange(4, 380, 12)
+    pts = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    pts = pts[rng.random(len(pts)) < 0.8].astype(np.int64)          # holes break the symmetry
+    infos = get_patch_info_one_img(0, 384, 0, 256, 3)
+    allq = build_all_patch_queries(pts, infos, 0, len(infos), cfg)
+    n_src = 0
+    for info, (a_ids, a_p, a_pairs, a_valid) in zip(infos, allq):
+        r_ids, r_p, r_pairs, r_valid = oscene.build_patch_queries(pts, info, AttrDict(cfg))
+        np.testing.assert_array_equal(a_ids, r_ids)
+        np.testing.assert_array_equal(a_valid, r_valid)
+        one = build_patch_queries(pts, *info[1], *info[2], cfg)
+        np.testing.assert_array_equal(one[2], r_pairs)               # the single-tile path is the reference's call verbatim
+        for i in range(len(a_ids)):
+            assert set(a_pairs[i, a_valid[i], 1].tolist()) == set(r_pairs[i, r_valid[i], 1].tolist()), (info, i)
+            n_src += 1
+    assert n_src > 500
+
+
 def test_sat2graph_format_kats():
     """The reference's own known-answer tests (graph_utils.py:687-702)."""
     nodes = np.array([[0.0, 0.0], [1.1, 1.1], [1.6, 1.6]])

@@ -68,6 +68,7 @@ struct srh_weights {
     f16 *neck0_w, *neck2_w; float *neck1_g, *neck1_b, *neck3_g, *neck3_b;
     f16 *dec0_w, *dec3_w, *dec5_w; float *dec0_b, *dec1_g, *dec1_b, *dec3_b, *dec5_b, *dec7_w, *dec7_b;
     f16 *tp_feat_w, *tp_pair_w; float *tp_feat_b, *tp_pair_b, *tp_out_w, *tp_out_b;
+    char* tp_stream = nullptr; float* tp_params = nullptr;       // fused trunk (topo_fused.hip)
     std::vector<TopoLayerW> tlayers;
 };
 
@@ -107,6 +108,13 @@ static int run(srh_ctx* c, const char* cls, double flops, double bytes, hipStrea
     hipEventRecord(pe.e1, s);
     c->prof.push_back(pe);
     return rc;
+}
+
+// SRH_TOPO_FUSED=0 selects the layer-by-layer TopoNet path (kept for A/B measurements and as a second implementation
+// the parity tests can compare against)
+static bool topo_fused() {
+    static const bool v = !(getenv("SRH_TOPO_FUSED") && atoi(getenv("SRH_TOPO_FUSED")) == 0);
+    return v;
 }
 
 static bool attn_fused() {
@@ -206,6 +214,66 @@ struct Packer {
         put_f16(dst, name, n, n, [](size_t i) { return (long)i; });
     }
 };
+
+// Weights of the fused TopoNet trunk (topo_fused.hip): every matrix cut into 16 (out) x 32 (in) MFMA A fragments of 1 KiB,
+// lane l = (row i = l & 15, k group g = l >> 4) holding 8 halves W[16 rt + i][k(kb, g, j)], in the exact order the kernel
+// consumes them.  pair_proj reads its input from memory, so k = 32 kb + 8 g + j; every later matrix reads activations that
+// are C-layout tile pairs of the previous MFMA, so k = 32 kb + 16 (j >> 2) + 4 g + (j & 3).
+static void pack_topo_fused(Packer& pk, srh_weights* w, int nl) {
+    const std::string T = "topo_net.";
+    const size_t nfrag = 80 + (size_t)192 * nl, nprm = 128 + (size_t)1280 * nl + 132;
+    const size_t soff = pk.alloc(nfrag * 1024), poff = pk.alloc(nprm * 4);
+    size_t f = 0;      // next fragment
+    auto frag = [&](const float* W, int ldw, int row0, int kb, bool perm, int kmax) {
+        f16* o = reinterpret_cast<f16*>(pk.host.data() + soff) + f * 512;
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, g = l >> 4;
+                const int k = perm ? 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3) : 32 * kb + 8 * g + j;
+                o[l * 8 + j] = (W && k < kmax) ? (f16)W[(size_t)(row0 + i) * ldw + k] : (f16)0.f;
+            }
+        ++f;
+    };
+    auto prm = [&](size_t at, const std::string& name, size_t n) {
+        const float* src = pk.get(name, n);
+        if (src) memcpy(pk.host.data() + poff + at * 4, src, n * 4);
+    };
+    {
+        const float* W = pk.get(T + "pair_proj.weight", 128 * 258);
+        for (int kb = 0; kb < 10; ++kb)
+            for (int rt = 0; rt < 8; ++rt) frag(W, 258, 16 * rt, kb, false, 258);
+    }
+    prm(0, T + "pair_proj.bias", 128);
+    for (int l = 0; l < nl; ++l) {
+        const std::string L = T + "transformer_encoder.layers." + std::to_string(l) + ".";
+        const size_t pb = 128 + (size_t)1280 * l;
+        {
+            const float* W = pk.get(L + "self_attn.in_proj_weight", 384 * 128);
+            for (int c = 0; c < 8; ++c)
+                for (int kb = 0; kb < 4; ++kb) frag(W, 128, 256 + 16 * c, kb, true, 128);                    // V
+            for (int h = 0; h < 4; ++h)
+                for (int i = 0; i < 4; ++i)                                                                  // Q 2h, Q 2h+1, K 2h, K 2h+1
+                    for (int kb = 0; kb < 4; ++kb) frag(W, 128, (i >> 1) * 128 + 16 * (2 * h + (i & 1)), kb, true, 128);
+        }
+        for (const char* m : {"self_attn.out_proj.weight", "linear1.weight", "linear2.weight"}) {
+            const float* W = pk.get(L + m, 128 * 128);
+            for (int rt = 0; rt < 8; ++rt)
+                for (int kb = 0; kb < 4; ++kb) frag(W, 128, 16 * rt, kb, true, 128);
+        }
+        prm(pb + 0, L + "self_attn.in_proj_bias", 384);
+        prm(pb + 384, L + "self_attn.out_proj.bias", 128);
+        prm(pb + 512, L + "norm1.weight", 128);
+        prm(pb + 640, L + "norm1.bias", 128);
+        prm(pb + 768, L + "linear1.bias", 128);
+        prm(pb + 896, L + "linear2.bias", 128);
+        prm(pb + 1024, L + "norm2.weight", 128);
+        prm(pb + 1152, L + "norm2.bias", 128);
+    }
+    prm(128 + (size_t)1280 * nl, T + "output_proj.weight", 128);
+    prm(128 + (size_t)1280 * nl + 128, T + "output_proj.bias", 1);
+    pk.slot(&w->tp_stream, soff);
+    pk.slot(&w->tp_params, poff);
+}
 }  // namespace
 
 extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
@@ -331,6 +399,7 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
     }
     pk.put_f32(&w->tp_out_w, T + "output_proj.weight", 128);
     pk.put_f32(&w->tp_out_b, T + "output_proj.bias", 1);
+    pack_topo_fused(pk, w, cfg->toponet_version != 2 ? 3 : 0);
 
     if (!pk.missing.empty()) {
         delete w;
@@ -549,6 +618,15 @@ extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embedd
     pg.pairs = pairs; pg.pairs_i64 = pairs_dtype == SRH_I64; pg.B = B; pg.N = N; pg.Ns = Ns; pg.Kp = K;
     pg.zero_offset = w->cfg.toponet_version == 1; pg.out = c->t_pair16.as<f16>(); pg.ld = 320;
     TRYK(c, "pair_gather", 0, (double)R * (512 + 640), s, launch_pair_gather(pg, s));
+    if (topo_fused()) {
+        // pair_proj + encoder layers + output_proj in one register-resident kernel (topo_fused.hip)
+        TopoFusedParams tf;
+        tf.pair = c->t_pair16.as<f16>(); tf.ld_pair = 320; tf.valid = valid; tf.stream = w->tp_stream; tf.params = w->tp_params;
+        tf.nlayers = (int)w->tlayers.size(); tf.nseq = B * Ns; tf.logits = logits; tf.scores = scores;
+        const double fl = (double)R * (2.0 * 320 * 128 + tf.nlayers * (2.0 * 128 * 768 + 4.0 * 16 * 128) + 256);
+        TRYK(c, "topo_fused", fl, 0, s, launch_topo_fused(tf, s));
+        return 0;
+    }
     GemmParams gp;
     gp.A = c->t_pair16.as<f16>(); gp.lda = 320; gp.W = w->tp_pair_w; gp.ldw = 320; gp.M = (int)R; gp.N = 128; gp.K = 320;
     gp.bias = w->tp_pair_b; gp.act = 2; gp.out_f32 = c->t_x.as<float>(); gp.ldc = 128;

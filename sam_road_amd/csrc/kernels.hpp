@@ -125,6 +125,17 @@ struct TopoAttnParams {
 };
 int launch_topo_attention(const TopoAttnParams& p, hipStream_t s);
 
+// fused TopoNet trunk (topo_fused.hip): pair rows -> logits / scores
+struct TopoFusedParams {
+    const f16* pair = nullptr; int ld_pair = 320;     // [nseq*16, ld_pair] gathered pair rows (src | tgt | dx dy | 0)
+    const uint8_t* valid = nullptr;                   // [nseq, 16]
+    const char* stream = nullptr;                     // packed MFMA fragments (api.hip pack_topo_fused)
+    const float* params = nullptr;                    // biases, LayerNorm affine, output_proj
+    int nlayers = 3, nseq = 0;
+    float* logits = nullptr; float* scores = nullptr; // [nseq*16], nullable
+};
+int launch_topo_fused(const TopoFusedParams& p, hipStream_t s);
+
 struct TopoOutParams {
     const float* x = nullptr;       // [rows,128] f32
     const float* w = nullptr; float b = 0.f;

@@ -156,6 +156,19 @@ int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t
 int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
                    const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads);
 
+/* Candidate pixels of a fused u8 mask: reference graph_extraction.py:24-28 (`np.where(mask > threshold)` and the scores
+ * there), row-major order.  Call with xy = scores = NULL to get *n, then again with xy int64 [n,2] (x, y) and scores u8 [n]
+ * (capacity = n). */
+int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float threshold, int64_t* xy, uint8_t* scores,
+                        int64_t capacity, int64_t* n);
+
+/* Directed edge votes of pass 2 (reference inferencer.py:209-221: dict of score sums / counts keyed by (src, tgt), filled in
+ * tile / point / slot order).  keys[i] = src * n_points + tgt, scores[i] in that visiting order.  Writes the unique keys in
+ * ascending order with their float64 sums — accumulated in the reference's order, hence bit-identical to its loop — and
+ * counts; out arrays have capacity n. */
+int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys, double* out_sums,
+                             double* out_counts, int64_t* n_unique);
+
 #ifdef __cplusplus
 }
 #endif

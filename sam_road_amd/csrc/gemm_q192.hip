@@ -44,12 +44,12 @@ constexpr int Q_LDS = Q_BIAS + 3 * 8192;          // 139264 B
 
 // virtual block vb (runs on XCD vb % 8; speed only) -> tile origin: every XCD owns a contiguous run of the tile
 // order, tiles ordered in groups of 4 tile rows with the column index outer (shared A / W panels stay in its L2)
-__device__ __forceinline__ void q_tile_of(int vb, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0) {
+__device__ __forceinline__ void q_tile_of(int vb, int ntiles, int tiles_m, int tiles_n, int& m0, int& n0, int GR = 4) {
     const int xcd = vb & 7, loc = vb >> 3;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int group = t / (4 * tiles_n), within = t - group * 4 * tiles_n;
-    const int first_m = group * 4, gsz = min(4, tiles_m - first_m);
+    const int group = t / (GR * tiles_n), within = t - group * GR * tiles_n;
+    const int first_m = group * GR, gsz = min(GR, tiles_m - first_m);
     m0 = (first_m + within % gsz) * 256;
     n0 = (within / gsz) * 192;
 }
@@ -122,8 +122,9 @@ void gemm_q192_kernel(GemmParams p) {
     // ---- tile bookkeeping (wave-uniform).  c_*: tile being computed; n_*: the tile after it (the DMA streams cross
     // into it one / two k-tiles early).  Stream A: W, X0 (+ the tile's bias at its first k-tile); stream B: X1.
     int c_m0, c_n0, c_slot = 0, n_m0 = 0, n_n0 = 0;
-    q_tile_of(blockIdx.x, ntiles, tiles_m, tiles_n, c_m0, c_n0);
-    if (my_tiles > 1) q_tile_of(blockIdx.x + G, ntiles, tiles_m, tiles_n, n_m0, n_n0);
+    const int GR = p.tile_gr > 0 ? p.tile_gr : 4;
+    q_tile_of(blockIdx.x, ntiles, tiles_m, tiles_n, c_m0, c_n0, GR);
+    if (my_tiles > 1) q_tile_of(blockIdx.x + G, ntiles, tiles_m, tiles_n, n_m0, n_n0, GR);
     int a_kt = 0, a_m0 = c_m0, a_n0 = c_n0, a_slot = 0;
     int b_kt = 0, b_m0 = c_m0;
     int p_slot = 0, p_soff = 0;                                   // finished tile: bias slot, byte offset of its origin in OUT16
@@ -365,7 +366,7 @@ void gemm_q192_kernel(GemmParams p) {
         p_soff = (c_m0 * p.ldc16 + c_n0) * 2; p_slot = c_slot;
         c_slot = c_slot == 2 ? 0 : c_slot + 1;
         c_m0 = n_m0; c_n0 = n_n0;
-        if (ti + 2 < my_tiles) q_tile_of(blockIdx.x + (ti + 2) * G, ntiles, tiles_m, tiles_n, n_m0, n_n0);
+        if (ti + 2 < my_tiles) q_tile_of(blockIdx.x + (ti + 2) * G, ntiles, tiles_m, tiles_n, n_m0, n_n0, GR);
     }
     if (g == 0) __builtin_amdgcn_s_barrier();                     // re-align the groups
     if (ABL == 3 && p.dbg && blockIdx.x == 0 && nq == 0 && lane == 0) {
@@ -445,6 +446,8 @@ int launch_gemm_q192(const GemmParams& p_in, hipStream_t stream, int ablation) {
     static const int env_prio = getenv("SRH_Q192_PRIO") ? atoi(getenv("SRH_Q192_PRIO")) : 0;
     GemmParams p = p_in;
     if (!p.prio_mode) p.prio_mode = env_prio;
+    static const int env_gr = getenv("SRH_Q192_GR") ? atoi(getenv("SRH_Q192_GR")) : 0;
+    if (!p.tile_gr) p.tile_gr = env_gr;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0; hipDeviceProp_t prop;

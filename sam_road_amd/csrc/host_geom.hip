@@ -148,3 +148,82 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     for (auto& th : pool) th.join();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Directed edge votes (reference inferencer.py:209-221: a Python dict keyed by (src, tgt) accumulating score sums and
+// counts over every valid pair of every tile, then mean > TOPO_THRESHOLD).  keys[i] = src * n_points + tgt and scores[i]
+// arrive in the reference's visiting order (tile, point, neighbour slot).  A STABLE LSD radix sort by key keeps that
+// order inside every key, so each sum is accumulated in float64 in exactly the reference's order: sums are bit-identical
+// to the dict loop.  Outputs (capacity n): unique keys ascending, their sums and counts; *n_unique = how many.
+// scratch: caller-provided, 2 * n int64 + n uint32 is NOT needed — the function allocates its own temporaries.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
+                                        double* out_sums, double* out_counts, int64_t* n_unique) {
+    if (n < 0 || !n_unique || (n > 0 && (!keys || !scores || !out_keys || !out_sums || !out_counts))) return SRH_ERR_BAD_ARG;
+    *n_unique = 0;
+    if (n == 0) return 0;
+    if (n > 0x7fffffffLL) return SRH_ERR_UNSUPPORTED;
+    int64_t kmax = 0;
+    for (int64_t i = 0; i < n; ++i) { if (keys[i] < 0) return SRH_ERR_BAD_ARG; kmax = std::max(kmax, keys[i]); }
+    std::vector<uint32_t> idx((size_t)n), tmp((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (uint32_t)i;
+    // 11-bit digits: 3 passes cover 2^33 (n_points up to ~92k); more passes only if the keys need them
+    const int BITS = 11, RAD = 1 << BITS;
+    std::vector<uint32_t> hist((size_t)RAD);
+    for (int shift = 0; shift < 63 && (kmax >> shift) != 0; shift += BITS) {
+        std::fill(hist.begin(), hist.end(), 0u);
+        for (int64_t i = 0; i < n; ++i) ++hist[(size_t)((keys[idx[(size_t)i]] >> shift) & (RAD - 1))];
+        uint32_t run = 0;
+        for (int d = 0; d < RAD; ++d) { const uint32_t c = hist[(size_t)d]; hist[(size_t)d] = run; run += c; }
+        for (int64_t i = 0; i < n; ++i) {
+            const uint32_t j = idx[(size_t)i];
+            tmp[(size_t)hist[(size_t)((keys[j] >> shift) & (RAD - 1))]++] = j;
+        }
+        idx.swap(tmp);
+    }
+    int64_t u = -1;
+    int64_t prev = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t j = idx[(size_t)i];
+        const int64_t k = keys[j];
+        if (k != prev) { ++u; out_keys[u] = k; out_sums[u] = 0.0; out_counts[u] = 0.0; prev = k; }
+        out_sums[u] += scores[j];
+        out_counts[u] += 1.0;
+    }
+    *n_unique = u + 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Candidate pixels of a fused u8 mask (reference graph_extraction.py:24-28: `np.where(mask > threshold)` + the scores at
+// those pixels), in np.where's row-major order.  Two-step protocol: call with xy = scores = NULL to get *n, allocate, call
+// again.  xy int64 [n, 2] as (x, y) = (column, row), scores u8 [n].  The threshold is the reference's float
+// (THRESHOLD * 255): a u8 value v is a candidate iff (float)v > threshold.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float threshold, int64_t* xy, uint8_t* scores,
+                                   int64_t capacity, int64_t* n) {
+    if (!mask || !n || H < 0 || W < 0 || ((xy == nullptr) != (scores == nullptr))) return SRH_ERR_BAD_ARG;
+    int first = 256;                      // smallest u8 value that passes
+    for (int v = 255; v >= 0; --v) { if ((float)v > threshold) first = v; else break; }
+    int64_t c = 0;
+    if (!xy) {
+        const size_t total = (size_t)H * (size_t)W;
+        for (size_t i = 0; i < total; ++i) c += mask[i] >= first;
+        *n = first > 255 ? 0 : c;
+        return 0;
+    }
+    if (first <= 255) {
+        for (int32_t y = 0; y < H; ++y) {
+            const uint8_t* row = mask + (size_t)y * W;
+            for (int32_t x = 0; x < W; ++x) {
+                if (row[x] >= first) {
+                    if (c >= capacity) return SRH_ERR_BAD_ARG;
+                    xy[2 * c] = x; xy[2 * c + 1] = y; scores[c] = row[x];
+                    ++c;
+                }
+            }
+        }
+    }
+    *n = c;
+    return 0;
+}

@@ -132,6 +132,54 @@ def test_queries_with_tied_cutoff_match_reference_kdtree():
     assert n_src > 500
 
 
+def test_mask_candidates_match_numpy_where():
+    """srh_mask_candidates == np.where(mask > thr) + mask[sel] (graph_extraction.py:24-28), incl. fractional thresholds,
+    nothing / everything above, and a non-square mask."""
+    from sam_road_amd.graph_points import points_and_scores_from_mask
+    rng = np.random.default_rng(5)
+    for shape, thr in [((257, 300), 63.24), ((64, 64), 254.5), ((64, 64), 255.0), ((50, 70), -1.0), ((128, 128), 0.0), ((33, 31), 92.82)]:
+        m = rng.integers(0, 256, size=shape).astype(np.uint8)
+        xy, sc = points_and_scores_from_mask(m, thr)
+        sel = m > thr
+        rc = np.column_stack(np.where(sel))
+        np.testing.assert_array_equal(xy, rc[:, ::-1])
+        np.testing.assert_array_equal(sc, m[sel])
+        assert xy.dtype == np.int64 and sc.dtype == np.uint8
+
+
+def test_edge_vote_accumulate_matches_reference_dict_loop():
+    """srh_edge_vote_accumulate == the reference's dict accumulation (inferencer.py:209-221), bit for bit: float64 sums in
+    visiting order per (src, tgt) key; also the empty and single-key edge cases."""
+    import ctypes as C
+    from collections import defaultdict
+    from sam_road_amd import _lib
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(k, s):
+        uk, su, cn = np.empty_like(k), np.empty_like(s), np.empty_like(s)
+        nu = C.c_int64(-1)
+        assert lib.srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(su), vp(cn), C.byref(nu)) == 0
+        return uk[:nu.value], su[:nu.value], cn[:nu.value]
+
+    rng = np.random.default_rng(11)
+    for n_pts, n in [(50, 4000), (5000, 200000), (70000, 30000), (3, 1)]:
+        src, tgt = rng.integers(0, n_pts, n), rng.integers(0, n_pts, n)
+        k = (src.astype(np.int64) * n_pts + tgt).astype(np.int64)
+        s = rng.random(n).astype(np.float32).astype(np.float64)
+        sums, cnts = defaultdict(float), defaultdict(float)
+        for kk, ss in zip(k.tolist(), s.tolist()):
+            sums[kk] += ss
+            cnts[kk] += 1.0
+        uk, su, cn = run(k, s)
+        want = sorted(sums)
+        np.testing.assert_array_equal(uk, want)
+        assert su.tolist() == [sums[q] for q in want]            # bit-identical float64 sums
+        assert cn.tolist() == [cnts[q] for q in want]
+    uk, su, cn = run(np.zeros(0, np.int64), np.zeros(0, np.float64))
+    assert uk.shape == (0,) and su.shape == (0,)
+
+
 def test_sat2graph_format_kats():
     """The reference's own known-answer tests (graph_utils.py:687-702)."""
     nodes = np.array([[0.0, 0.0], [1.1, 1.1], [1.6, 1.6]])

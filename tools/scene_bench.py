@@ -5,7 +5,7 @@ Reports ms per scene for pass 1 alone (crop -> encoder -> decoder -> fused u8 ma
 whole infer_one_img (pass 1 + host NMS + pass-2 queries + TopoNet + edge vote).  The final map_decoder bias is
 lowered so that the random network yields sparse masks (a few thousand graph points, as a trained one does).
 
-    python tools/scene_bench.py [--bias -2.2] [--batch 64] [--iters 3]
+    python tools/scene_bench.py [--bias -2.2] [--wscale 16] [--batch 64] [--iters 3]
 """
 import argparse
 import json
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--bias", type=float, default=-2.2)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--wscale", type=float, default=0.5)
+    ap.add_argument("--wscale", type=float, default=16.0)   # spread of the final layer: with 16 the random net yields ~4k graph points
     args = ap.parse_args()
     from sam_road_amd import Config, SAMRoad
     from sam_road_amd.inferencer import infer_one_img

@@ -105,6 +105,7 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     auto work = [&](int32_t t_begin, int32_t t_end) {
         std::vector<int64_t> lx, ly;
         std::vector<std::pair<int64_t, int32_t>> cand;
+        std::vector<int32_t> cstart, cfill, pcell, corder;
         for (int32_t t = t_begin; t < t_end; ++t) {
             const int64_t x0 = boxes[4 * t], y0 = boxes[4 * t + 1], x1 = boxes[4 * t + 2], y1 = boxes[4 * t + 3];
             int64_t* tid = ids + offsets[t];
@@ -116,14 +117,31 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
             }
             const int32_t m = (int32_t)lx.size();
             uint8_t* tamb = ambiguous + offsets[t];
+            // uniform grid over the tile, cell side = radius: the neighbours of a point lie in its 3 x 3 cell block
+            const int64_t cell = std::max<int64_t>(radius, 1);
+            const int32_t gw = (int32_t)((x1 - x0) / cell) + 1, gh = (int32_t)((y1 - y0) / cell) + 1;
+            cstart.assign((size_t)gw * gh + 1, 0);
+            pcell.resize((size_t)m);
+            for (int32_t i = 0; i < m; ++i) {
+                pcell[(size_t)i] = (int32_t)((ly[i] - y0) / cell) * gw + (int32_t)((lx[i] - x0) / cell);
+                ++cstart[(size_t)pcell[(size_t)i] + 1];
+            }
+            for (size_t c = 0; c < (size_t)gw * gh; ++c) cstart[c + 1] += cstart[c];
+            corder.resize((size_t)m);
+            cfill.assign(cstart.begin(), cstart.end() - 1);
+            for (int32_t i = 0; i < m; ++i) corder[(size_t)cfill[(size_t)pcell[(size_t)i]]++] = i;
             for (int32_t i = 0; i < m; ++i) {
                 bool amb = false;
                 cand.clear();
-                for (int32_t j = 0; j < m; ++j) {
-                    if (j == i) continue;
-                    const int64_t dx = lx[j] - lx[i], dy = ly[j] - ly[i], d2 = dx * dx + dy * dy;
-                    if (d2 < r2) cand.emplace_back(d2, j);
-                }
+                const int32_t cx = pcell[(size_t)i] % gw, cy = pcell[(size_t)i] / gw;
+                for (int32_t yy = std::max(cy - 1, 0); yy <= std::min(cy + 1, gh - 1); ++yy)
+                    for (int32_t xx = std::max(cx - 1, 0); xx <= std::min(cx + 1, gw - 1); ++xx)
+                        for (int32_t q = cstart[(size_t)yy * gw + xx]; q < cstart[(size_t)yy * gw + xx + 1]; ++q) {
+                            const int32_t j = corder[(size_t)q];
+                            if (j == i) continue;
+                            const int64_t dx = lx[j] - lx[i], dy = ly[j] - ly[i], d2 = dx * dx + dy * dy;
+                            if (d2 < r2) cand.emplace_back(d2, j);
+                        }
                 const size_t keep = std::min<size_t>((size_t)K, cand.size());
                 if (cand.size() > (size_t)K) {
                     std::partial_sort(cand.begin(), cand.begin() + K + 1, cand.end());

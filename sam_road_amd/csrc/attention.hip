@@ -654,7 +654,9 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
     if (!p.ablate) p.ablate = env_abl;
     const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32)));
-    if (!mfma_path) {      // other head dims (ViT-H) and the 64x64 global window of 1024-pixel tiles
+    static const bool use_hdx = !(getenv("SRH_ATTN_HDX") && atoi(getenv("SRH_ATTN_HDX")) == 0);
+    if (!mfma_path && use_hdx && attention_hdx_supported(p)) return launch_attention_hdx(p, s);
+    if (!mfma_path) {      // other head dims / windows (ViT-H at 512 px, the 64x64 global window of 1024-pixel tiles)
         if ((p.hd != 64 && p.hd != 80) || !p.table_h || !p.table_w || p.win > 64) return -2;
         const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
         const int lds = (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 6 + 256 * 2 * p.win * 4;

@@ -1,0 +1,264 @@
+// MFMA attention for head dims other than 64 on small windows (ViT-H: head dim 80; 14x14 windows and the 16x16 global
+// window of 256-pixel tiles, i.e. BASELINE configs[4] toponet_vith_256.yaml).  Same semantics and the same transposed
+// one-lane-per-query formulation as attention.hip (S^T = K Q^T, O^T = V^T P^T with v_mfma_f32_32x32x16_f16, rel_w as the
+// C operand of the first S MFMA, rel_h folded into the row max / exp addend, pad tokens are real keys with k = b_k,
+// v = b_v, pad queries are skipped), generalised over the number of 16-wide k steps (KS = HD / 16 = 5) and of 32-row
+// O^T tiles (NDT = ceil(HD / 32) = 3, rows HD..95 are zero rows of V^T).  All keys of the window (<= 256) are staged in
+// LDS once per (image, head, window): K rows with a 16-byte pad (176-byte stride: 16 consecutive rows start in 16
+// different 4-bank groups, so the ds_read_b128 fragment reads are conflict-free without a swizzle), V^T tiles in
+// attention.hip's key-permuted layout.  This replaces the f32 VALU fallback (attn_generic_kernel), which took 7.3 of the
+// 14.4 ms of a ViT-H step.  Correctness-first staging (scalar transposition of V through ds_write_b16), tuned MFMA body.
+#include <cstdlib>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace srh {
+namespace {
+
+template <int WIN> struct GeomX;
+template <> struct GeomX<14> { static constexpr int KPT = 28, RPT = 2, NT = 7; };
+template <> struct GeomX<16> { static constexpr int KPT = 32, RPT = 2, NT = 8; };
+
+// local MFMA row i of a key tile -> (row-in-tile, col) of the window
+template <int WIN> __device__ __forceinline__ void hx_tile_rc(int i, int& r, int& c) {
+    if (WIN == 16) { r = i >> 4; c = i & 15; }
+    else { r = i >= 14; c = i - 14 * r; }
+}
+// V^T slot of local key i: the key permutation that makes exp(S^T) registers the P^T B-fragment (attention.hip vt_slot)
+__device__ __forceinline__ int hx_vt_slot(int i) {
+    const int half = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
+    return ((reg >> 3) * 2 + half) * 8 + (reg & 7);
+}
+
+template <int KS, int NDT>
+struct QStateX {
+    f16x8 q[KS];
+    f32x16 relw;
+    float m, l;
+    f32x16 o[NDT];
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one 32-row key tile (see attention.hip attn_tile; identical arithmetic with KS k steps and NDT output tiles)
+template <int WIN, int KS, int NDT>
+__device__ __forceinline__ void hx_tile(QStateX<KS, NDT>& st, const f16x8 (&kf)[KS], const char* vt_lds, float rh0, float rh1,
+                                        float c_exp, int lane) {
+    const int half = lane >> 5, row = lane & 31;
+    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) s = mfma32(kf[ks], st.q[ks], s);
+    f16x8 vf[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const int c = (sx * 2 + half) ^ ((row >> 2) & 3);
+            vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + dt * 2048 + row * 64 + c * 16);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    const float rhm = WIN == 14 ? (half ? rh1 : rh0) : rh0;
+    float mloc;
+    if (WIN == 16) {
+        float ma = s[0], mb = s[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, s[r]); mb = fmaxf(mb, s[8 + r]); }
+        mloc = fmaxf(ma + rh0, mb + rh1);
+    } else {
+        float ma = s[0], mb = s[8];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) ma = fmaxf(ma, s[r]);
+#pragma unroll
+        for (int r = 9; r < 12; ++r) mb = fmaxf(mb, s[r]);
+        const float mt = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
+        mb = fmaxf(mb, half ? -INFINITY : mt);                   // rows 28..31 are not keys
+        mloc = fmaxf(fmaxf(ma + rh0, mb + rh1), fmaxf(s[6], s[7]) + rhm);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(st.m, mloc);
+    if (__any(m_new != st.m)) {
+        const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c_exp);
+        st.l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+        st.m = m_new;
+    }
+    const float mc = -m_new * c_exp;
+    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
+    const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;
+    float sum = 0.f;
+    f16x8 pb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float ad = WIN == 16 ? (r >= 8 ? mc1 : mc0) : (r < 6 ? mc0 : r < 8 ? mcm : r < 12 ? mc1 : mct);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c_exp, ad));
+        sum += pv;
+        pb[r >> 3][r & 7] = (f16)pv;
+    }
+    st.l += sum;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) st.o[dt] = mfma32(vf[dt][sx], pb[sx], st.o[dt]);
+}
+
+// grid = (image, head, window); 4 waves; each wave walks 32-query tiles of the window's REAL tokens
+template <int HD, int WIN>
+__global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
+    constexpr int KS = HD / 16, NDT = (HD + 31) / 32, NT = GeomX<WIN>::NT, KPT = GeomX<WIN>::KPT, RPT = GeomX<WIN>::RPT;
+    constexpr int KROW = HD * 2 + 16, NCH = HD / 8;
+    constexpr int LDS_K = NT * 32 * KROW, LDS_VT = NT * NDT * 2048;
+    static_assert(HD % 16 == 0 && KROW % 16 == 0, "head dim must be a multiple of 16");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const k_lds = smem;
+    char* const vt_lds = smem + LDS_K;
+    float* const rh_lds = reinterpret_cast<float*>(smem + LDS_K + LDS_VT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int S = p.S, D = p.heads * HD;
+    const int nw = WIN == 14 ? (S + WIN - 1) / WIN : 1;
+    int u = blockIdx.x;
+    const int head = u % p.heads; u /= p.heads;
+    const int widx = u % (nw * nw); u /= (nw * nw);
+    const int b = u;
+    const int wy = widx / nw, wx = widx % nw;
+    const int nry = min(WIN, S - wy * WIN), nrx = min(WIN, S - wx * WIN);
+    const int nreal = nry * nrx;
+    const int ntq = (nreal + 31) / 32;
+
+    // ---- stage K rows and the transposed, key-permuted V^T tiles (pad positions: k = b_k, v = b_v; rows KPT..31 and the
+    // V^T rows HD..32*NDT-1 are zero)
+    for (int i = tid; i < LDS_VT / 16; i += 256) reinterpret_cast<uint4*>(vt_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int item = tid; item < NT * 32 * NCH; item += 256) {
+        const int c = item % NCH, i = (item / NCH) & 31, t = item / (NCH * 32);
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (i < KPT) {
+            int rr, cc;
+            hx_tile_rc<WIN>(i, rr, cc);
+            const int y = wy * WIN + t * RPT + rr, x = wx * WIN + cc;
+            const f16* src = (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld : p.bias_qkv;
+            kv = *reinterpret_cast<const uint4*>(src + D + head * HD + c * 8);
+            vv = *reinterpret_cast<const uint4*>(src + 2 * D + head * HD + c * 8);
+        }
+        *reinterpret_cast<uint4*>(k_lds + (t * 32 + i) * KROW + c * 16) = kv;
+        if (i < KPT) {
+            const int slot = hx_vt_slot(i);
+            const f16* vh = reinterpret_cast<const f16*>(&vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = c * 8 + e, dt = d >> 5, dl = d & 31;
+                *reinterpret_cast<f16*>(vt_lds + (t * NDT + dt) * 2048 + dl * 64 + (((slot >> 3) ^ ((dl >> 2) & 3)) * 16) + (slot & 7) * 2) = vh[e];
+            }
+        }
+    }
+    __syncthreads();
+
+    const float c_exp = p.scale * 1.4426950408889634f;
+    const float inv_scale = 1.0f / p.scale;
+    float* const rh = rh_lds + wave * 32 * 17;
+    for (int jt = wave; jt < ntq; jt += 4) {
+        const int qi_raw = jt * 32 + (lane & 31);
+        const bool valid = qi_raw < nreal;
+        const int qi = valid ? qi_raw : nreal - 1;
+        const int ry = qi / nrx, rx = qi % nrx;
+        const size_t tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
+        QStateX<KS, NDT> st;
+        const f16* q = p.qkv + tok * p.ld + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) st.q[ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
+        st.m = -INFINITY;
+        st.l = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
+        // fused decomposed rel-pos bias (attention.hip fused_relpos): table rows x Q via MFMA, scattered to the wave's
+        // LDS table; the w part becomes the 16 tile-invariant per-lane values, the h part stays in LDS (2 per tile)
+        const int jrow_t = min(lane & 31, 2 * WIN - 2);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const f16* table = pass == 0 ? p.table_w : p.table_h;
+            const int qc = pass == 0 ? rx : ry;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(table + (size_t)jrow_t * HD + (ks * 2 + half) * 8);
+                acc = mfma32(a, st.q[ks], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jrow = mfma32_row(r, lane);
+                const int k = qc - jrow + WIN - 1;
+                if (k >= 0 && k < WIN && jrow < 2 * WIN - 1) rh[(lane & 31) * 17 + k] = acc[r] * inv_scale;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (pass == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int rr, cc;
+                    hx_tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
+                    st.relw[r] = (cc < WIN) ? rh[(lane & 31) * 17 + cc] : 0.f;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f16x8 kf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kf[ks] = *reinterpret_cast<const f16x8*>(k_lds + (t * 32 + (lane & 31)) * KROW + (ks * 2 + half) * 16);
+            const float rh0 = rh[(lane & 31) * 17 + t * RPT], rh1 = rh[(lane & 31) * 17 + t * RPT + 1];
+            hx_tile<WIN, KS, NDT>(st, kf, vt_lds + t * NDT * 2048, rh0, rh1, c_exp, lane);
+        }
+        const float inv = 1.0f / (st.l + __shfl_xor(st.l, 32, 64));
+        if (valid) {
+            f16* o = p.out + tok * p.ldo + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int d0 = dt * 32 + 8 * qd + 4 * half;
+                    if (d0 < HD) {
+                        f16x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (f16)(st.o[dt][qd * 4 + e] * inv);
+                        *reinterpret_cast<f16x4*>(o + d0) = h;
+                    }
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int HD, int WIN>
+int hdx_launch(const AttnParams& p, hipStream_t s) {
+    constexpr int NDT = (HD + 31) / 32, NT = GeomX<WIN>::NT;
+    constexpr int lds = NT * 32 * (HD * 2 + 16) + NT * NDT * 2048 + 4 * 32 * 17 * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_hdx_kernel<HD, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    const int nw = WIN == 14 ? (p.S + WIN - 1) / WIN : 1;
+    const int grid = p.B * p.heads * nw * nw;
+    hipLaunchKernelGGL((attn_hdx_kernel<HD, WIN>), dim3(grid), dim3(256), lds, s, p);
+    return SRH_CHECK_LAUNCH();
+}
+}  // namespace
+
+bool attention_hdx_supported(const AttnParams& p) {
+    return p.hd == 80 && p.table_h && p.table_w && !p.rel && (p.win == 14 || (p.win == 16 && p.S == 16));
+}
+
+int launch_attention_hdx(const AttnParams& p, hipStream_t s) {
+    if (!attention_hdx_supported(p)) return -2;
+    return p.win == 14 ? hdx_launch<80, 14>(p, s) : hdx_launch<80, 16>(p, s);
+}
+
+}  // namespace srh

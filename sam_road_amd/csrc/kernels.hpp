@@ -75,6 +75,9 @@ struct AttnParams {
     int ablate = 0;                         // tuning aid (env SRH_ATTN_ABL): 1 no key loop, 2 no K/V staging, 3 no fused rel-pos
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
+// attention_hdx.hip: MFMA attention for head dim 80 on 14x14 windows / the 16x16 global window (ViT-H at 256 px)
+bool attention_hdx_supported(const AttnParams& p);
+int launch_attention_hdx(const AttnParams& p, hipStream_t s);
 
 // map_decoder last stage: ConvT(32->2,k2s2) + sigmoid + quad-tree -> NHWC scatter.
 struct DecodeOutParams {

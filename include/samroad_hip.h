@@ -31,7 +31,7 @@ extern "C" {
 typedef enum {
     SRH_OK = 0,
     SRH_ERR_BAD_ARG = -1,      /* null pointer, bad dtype code, bad shape */
-    SRH_ERR_UNSUPPORTED = -2,  /* configuration not built (e.g. head_dim 80, USE_SAM_DECODER) */
+    SRH_ERR_UNSUPPORTED = -2,  /* configuration not built (e.g. head_dim other than 64 / 80, USE_SAM_DECODER) */
     SRH_ERR_HIP = -3,          /* HIP runtime error (text in srh_last_error) */
     SRH_ERR_MISSING_WEIGHT = -4,
     SRH_ERR_NO_DEVICE = -5

@@ -22,7 +22,7 @@
 
 namespace srh {
 
-constexpr int HD = 64;  // head dim of ViT-B / ViT-L (ViT-H's 80 is not built yet)
+constexpr int HD = 64;  // head dim of ViT-B / ViT-L (ViT-H's 80: attention_hdx.hip, else attn_generic_kernel below)
 
 template <int WIN> struct Geom;
 template <> struct Geom<14> { static constexpr int KPT = 28, RPT = 2, NT = 7, WP = 16; };

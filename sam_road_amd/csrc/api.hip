@@ -39,7 +39,7 @@ struct srh_ctx {
     std::string err;
     // encoder / decoder workspace
     DevBuf a0, x, xn16, delta16, qkv16, rel, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16, d2_16;
-    DevBuf scores_ws, emb_ws, counter;
+    DevBuf scores_ws, emb_ws, counter, split_ws;
     // toponet workspace
     DevBuf t_feat16, t_pf16, t_pair16, t_x, t_x16, t_qkv16, t_at16, t_y, t_h16;
     // profiling
@@ -122,7 +122,13 @@ static bool attn_fused() {
     return v;
 }
 
-static int gemm(srh_ctx* c, const char* cls, const GemmParams& p, hipStream_t s) {
+static int gemm(srh_ctx* c, const char* cls, const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    const int sk = gemm_splitk_factor(p);
+    if (sk > 1) {       // small-M layers (ViT-L / ViT-H at 256 px): deterministic split-K through a ctx-owned f32 workspace
+        if (c->split_ws.ensure((size_t)sk * p.M * p.N * 4)) return fail(c, SRH_ERR_HIP, "split-K workspace allocation failed");
+        p.splitk = sk; p.split_ws = c->split_ws.as<float>();
+    }
     const double fl = 2.0 * p.M * (double)p.N * p.K;
     const int rc = run(c, cls, fl, 0.0, s, [&] { return launch_gemm(p, s); });
     if (rc) return fail(c, rc == -2 ? SRH_ERR_UNSUPPORTED : SRH_ERR_HIP, std::string("gemm ") + cls + " launch failed");

@@ -184,7 +184,9 @@ void gemm_glds_kernel(GemmParams p) {
     int tile_m, tile_n;
     tile_of_block<8>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.K / BK;
+    // split-K: workgroup z = blockIdx.y of splitk handles k-tiles [kt0, kt1)
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, zsplit = blockIdx.y;
+    const int kt0 = zsplit * (p.K / BK) / nsplit, nk = (zsplit + 1) * (p.K / BK) / nsplit;
 
     // DMA piece i (0..3) of a wave covers rows i*32 + wave*8 .. +8 of the tile, 8 rows x 128 B = 1 KiB
     const int prow = lane >> 3, pc = lane & 7;
@@ -220,11 +222,11 @@ void gemm_glds_kernel(GemmParams p) {
     for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
     const int w_row0 = (wn * 64) * 128, x_row0 = (wm * 64) * 128;
 
-    if (NST == 2) SRH_DMA_TILE(0, 0)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = NST == 2 ? (kt & 1) : 0;
+    if (NST == 2) SRH_DMA_TILE(kt0, 0)
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int stage = NST == 2 ? ((kt - kt0) & 1) : 0;
         if (NST == 1) {
-            if (kt > 0) __syncthreads();           // everyone finished reading the single stage
+            if (kt > kt0) __syncthreads();           // everyone finished reading the single stage
             SRH_DMA_TILE(kt, 0)
             __syncthreads();                       // vmcnt(0) + barrier: the tile has landed
         } else {
@@ -259,7 +261,38 @@ void gemm_glds_kernel(GemmParams p) {
     }
     if (NST == 1) { epilogue<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane); return; }
     __syncthreads();   // every wave is done reading operand tiles: LDS becomes epilogue staging space
+    if (nsplit > 1) {  // raw f32 partial sums; bias / residual / activation are applied by splitk_reduce_kernel
+        GemmParams q = p;
+        q.bias = nullptr; q.resid = nullptr; q.pos = nullptr; q.act = 0; q.out_f16 = nullptr;
+        q.out_f32 = p.split_ws + (size_t)zsplit * p.M * p.N; q.ldc = p.N;
+        epilogue_staged<2, 0>(q, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+        return;
+    }
     epilogue_staged<2, 0>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// out = act(sum_z partial[z] + bias) (+ resid): the partial sums are added in ascending z (fixed order: deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+    const size_t quad = (size_t)blockIdx.x * 256 + threadIdx.x;          // 4 consecutive columns
+    const size_t total = (size_t)p.M * p.N / 4;
+    if (quad >= total) return;
+    const int m = (int)(quad / (p.N / 4)), n = (int)(quad % (p.N / 4)) * 4;
+    const size_t MN = (size_t)p.M * p.N;
+    float4 a = *reinterpret_cast<const float4*>(p.split_ws + (size_t)m * p.N + n);
+    for (int z = 1; z < p.splitk; ++z) {
+        const float4 b = *reinterpret_cast<const float4*>(p.split_ws + z * MN + (size_t)m * p.N + n);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    if (p.act == 1) { for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]); }
+    else if (p.act == 2) { for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f); }
+    if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+    if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.out_f16) {
+        const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -731,6 +764,20 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
+int gemm_splitk_factor(const GemmParams& p) {
+    static const bool on = !(getenv("SRH_GEMM_SPLITK") && atoi(getenv("SRH_GEMM_SPLITK")) == 0);
+    if (!on || p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
+    if (p.M >= 4096 || q192_preferred(p)) return 1;
+    const long tiles = (long)(p.M / 128) * (p.N / 128);
+    const int nk = p.K / BK;
+    if (tiles >= 224 || nk < 16) return 1;
+    int s = (int)(512 / tiles);
+    if (s > 4) s = 4;
+    while (s > 1 && nk / s < 6) --s;
+    return s;
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
     if (p.N % 128 != 0 || p.K % BK != 0) return -2;
@@ -785,6 +832,13 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);
+    if (variant == 0 && p.split_ws && p.splitk > 1) {
+        if (p.splitk != gemm_splitk_factor(p)) return -2;
+        hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid, p.splitk), dim3(256), 65536, stream, p);
+        const size_t quads = (size_t)p.M * p.N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (variant == 11) hipLaunchKernelGGL((gemm_glds_kernel<1, 2>), dim3(grid), dim3(256), 65536, stream, p);
     else if (variant == 12) hipLaunchKernelGGL((gemm_glds_kernel<2, 2>), dim3(grid), dim3(256), 65536, stream, p);
     else if (variant == 4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1>), dim3(grid), dim3(256), 65536 / 2, stream, p);

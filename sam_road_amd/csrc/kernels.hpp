@@ -19,8 +19,13 @@ struct GemmParams {
     int prio_mode = 0;                         // tuning aid (env SRH_Q192_PRIO): 0 s_setprio 1 around the MFMA segment, 1 none, 2 around the read segment
     unsigned long long* dbg = nullptr;         // tuning aid (gemm_q192 ablation 3): per-segment cycle sums
     int variant = 0;                           // 0 LDS-DMA 128x128 (default), 1 register-staged 128x128, 2 register-staged 256x256
+    // split-K for layers with too few 128x128 tiles to fill the chip (small M: ViT-L / ViT-H at 256 px): splitk workgroups
+    // per tile write f32 partials to split_ws [splitk, M, N]; a second kernel sums them in a fixed order (deterministic)
+    // and applies bias / residual / activation.  0 / 1 = off.
+    int splitk = 0; float* split_ws = nullptr;
 };
 int launch_gemm(const GemmParams& p, hipStream_t s);
+int gemm_splitk_factor(const GemmParams& p);   // what launch_gemm would use if a workspace were provided (1 = no split)
 // persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip); fp16 output, no residual / pos-embed
 bool q192_supported(const GemmParams& p);
 bool q192_preferred(const GemmParams& p);

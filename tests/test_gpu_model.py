@@ -130,3 +130,51 @@ def test_u8_and_f32_inputs_agree():
     s0, e0 = net.infer_masks_and_img_features(rgb.cuda())
     s1, e1 = net.infer_masks_and_img_features(rgb.to(torch.uint8).cuda())
     assert torch.equal(e0, e1) and torch.equal(s0, s1)
+
+
+def test_full_size_properties_baseline_config():
+    """BASELINE configs[1] at its full size (B = 16 tiles of 512^2, ViT-B, all 12 blocks) — too big for the CPU oracle, so
+    the size-independent properties of the path are checked instead: (1) bit-exact determinism, (2) tiles of a batch are
+    independent: permuting the tiles permutes the outputs bit-exactly, (3) a tile's result does not depend on the batch it
+    travels in beyond kernel-selection rounding (B = 16 takes the persistent q192 GEMMs, B = 2 the 128x128 kernels)."""
+    _, net = build_pair(CFG512)
+    rgb = synth_tiles(16, 512, seed=9).cuda()
+    s0, e0 = net.infer_masks_and_img_features(rgb)
+    s1, e1 = net.infer_masks_and_img_features(rgb)
+    assert torch.isfinite(s0).all() and torch.isfinite(e0).all()
+    assert torch.equal(s0, s1) and torch.equal(e0, e1)
+    perm = torch.tensor([5, 0, 11, 3, 15, 8, 1, 13, 2, 7, 10, 4, 14, 6, 9, 12], device="cuda")
+    sp, ep = net.infer_masks_and_img_features(rgb[perm].contiguous())
+    assert torch.equal(sp, s0[perm]) and torch.equal(ep, e0[perm])
+    s2, e2 = net.infer_masks_and_img_features(rgb[:2].contiguous())
+    assert rel_l2(e2.float().cpu(), e0[:2].float().cpu()) < 3e-3
+    assert (s2 - s0[:2]).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("version", ["normal", "no_offset", "no_transformer"])
+def test_toponet_ragged_and_variants(version):
+    """TopoNet (fused trunk) vs the oracle on ragged shapes: 3 tiles x 37 source points (111 sequences: the last workgroup
+    of the fused kernel is partly empty), sequences with no valid pair at all (model.py:129-130 flip), points outside the
+    tile, for every TOPONET_VERSION."""
+    cfg = CFG256 | dict(ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[], TOPONET_VERSION=version)
+    oracle, net = build_pair(cfg, seed=21)
+    g = torch.Generator().manual_seed(5)
+    B, N, K = 3, 37, 16
+    emb = torch.randn(B, 256, 16, 16, generator=g)
+    points = torch.randint(-8, 264, (B, N, 2), generator=g)
+    pairs = torch.stack([torch.arange(N)[None, :, None].expand(B, N, K), torch.randint(0, N, (B, N, K), generator=g)], -1)
+    valid = torch.rand(B, N, K, generator=g) < 0.6
+    valid[0, 3] = False
+    valid[2, 36] = False
+    valid[1, 0] = True
+    with torch.no_grad():
+        feats = oracle.bilinear_sampler(emb, points)
+        _, ts_r = oracle.topo_net(points, feats, pairs, valid)
+    ts = net.infer_toponet(emb.cuda(), points.cuda(), pairs.cuda(), valid.cuda()).cpu()
+    assert tuple(ts.shape) == (B, N, K, 1) and torch.isfinite(ts).all()
+    v = valid.clone()
+    v[0, 3] = True          # flipped rows: every key takes part, every score is defined
+    v[2, 36] = True
+    err = (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item()
+    print(version, "max abs", err)
+    assert err < 1e-2

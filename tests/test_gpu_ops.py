@@ -26,7 +26,9 @@ def _sync():
 
 
 @pytest.mark.parametrize("M,N,K,act,resid", [(256, 128, 64, 0, False), (300, 256, 192, 1, False),
-                                              (1000, 768, 768, 0, True), (128, 384, 3072, 2, False)])
+                                              (1000, 768, 768, 0, True), (128, 384, 3072, 2, False),
+                                              # small-M layers of ViT-H at 256 px: the deterministic split-K path (3 / 4 K-slices)
+                                              (2048, 1280, 5120, 0, True), (2048, 1280, 1280, 1, False), (256, 768, 3072, 0, True)])
 def test_gemm(ctx, M, N, K, act, resid):
     g = torch.Generator().manual_seed(M + N + K)
     A = (torch.randn(M, K, generator=g) * 0.5).half()
@@ -53,6 +55,11 @@ def test_gemm(ctx, M, N, K, act, resid):
     scale = ref.abs().max().item()
     assert err <= 2e-4 * max(scale, 1.0) * (K / 64) ** 0.5, (err, scale)
     assert (o16.cpu().float() - ref).abs().max().item() <= 2e-3 * max(scale, 1.0)
+    # the same call again gives the same bits (split-K partial sums are added in a fixed order)
+    o32b = torch.full((M, N), float("nan"), device="cuda")
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(dA), _p(dW), _p(db), _p(dR), M, N, K, act, _p(o32b), None, None), "srh_op_gemm")
+    _sync()
+    assert torch.equal(o32, o32b)
 
 
 @pytest.mark.parametrize("M,N,K,act,use_bias", [

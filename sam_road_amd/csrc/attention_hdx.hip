@@ -6,8 +6,8 @@
 // O^T tiles (NDT = ceil(HD / 32) = 3, rows HD..95 are zero rows of V^T).  All keys of the window (<= 256) are staged in
 // LDS once per (image, head, window): K rows with a 16-byte pad (176-byte stride: 16 consecutive rows start in 16
 // different 4-bank groups, so the ds_read_b128 fragment reads are conflict-free without a swizzle), V^T tiles in
-// attention.hip's key-permuted layout.  This replaces the f32 VALU fallback (attn_generic_kernel), which took 7.3 of the
-// 14.4 ms of a ViT-H step.  Correctness-first staging (scalar transposition of V through ds_write_b16), tuned MFMA body.
+// attention.hip's key-permuted layout (4-key x 8-dim blocks transposed with v_perm_b32).  This replaces the f32 VALU
+// fallback (attn_generic_kernel), which took 7.3 of the 14.4 ms of a ViT-H step.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -130,28 +130,49 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
 
     // ---- stage K rows and the transposed, key-permuted V^T tiles (pad positions: k = b_k, v = b_v; rows KPT..31 and the
     // V^T rows HD..32*NDT-1 are zero)
-    for (int i = tid; i < LDS_VT / 16; i += 256) reinterpret_cast<uint4*>(vt_lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    // zero rows of V^T: d = HD .. 32 * NDT - 1 of every tile (the O^T rows that do not exist)
+    if (HD % 32 != 0) {
+        constexpr int ZROWS = 32 * NDT - HD;                     // rows HD % 32 .. 31 of the last d tile, 64 B each
+        for (int i = tid; i < NT * ZROWS * 4; i += 256) {
+            const int t = i / (ZROWS * 4), q = i % (ZROWS * 4);
+            reinterpret_cast<uint4*>(vt_lds + (t * NDT + NDT - 1) * 2048 + (HD % 32) * 64)[q] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    auto key_src = [&](int t, int i) -> const f16* {             // qkv row of local key i of tile t (pad position: the bias row)
+        int rr, cc;
+        hx_tile_rc<WIN>(i, rr, cc);
+        const int y = wy * WIN + t * RPT + rr, x = wx * WIN + cc;
+        return (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld : p.bias_qkv;
+    };
     for (int item = tid; item < NT * 32 * NCH; item += 256) {
         const int c = item % NCH, i = (item / NCH) & 31, t = item / (NCH * 32);
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (i < KPT) {
-            int rr, cc;
-            hx_tile_rc<WIN>(i, rr, cc);
-            const int y = wy * WIN + t * RPT + rr, x = wx * WIN + cc;
-            const f16* src = (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld : p.bias_qkv;
-            kv = *reinterpret_cast<const uint4*>(src + D + head * HD + c * 8);
-            vv = *reinterpret_cast<const uint4*>(src + 2 * D + head * HD + c * 8);
-        }
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (i < KPT) kv = *reinterpret_cast<const uint4*>(key_src(t, i) + D + head * HD + c * 8);
         *reinterpret_cast<uint4*>(k_lds + (t * 32 + i) * KROW + c * 16) = kv;
-        if (i < KPT) {
-            const int slot = hx_vt_slot(i);
-            const f16* vh = reinterpret_cast<const f16*>(&vv);
+    }
+    // V: 4 keys x 8 dims per item -> 8 dims x 4 keys: every output word pairs the same fp16 of two keys = one v_perm_b32
+    for (int item = tid; item < NT * 8 * NCH; item += 256) {
+        const int c = item % NCH, kq = (item / NCH) & 7, t = item / (NCH * 8);
+        uint4 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = c * 8 + e, dt = d >> 5, dl = d & 31;
-                *reinterpret_cast<f16*>(vt_lds + (t * NDT + dt) * 2048 + dl * 64 + (((slot >> 3) ^ ((dl >> 2) & 3)) * 16) + (slot & 7) * 2) = vh[e];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int i = kq * 4 + j;
+            v[j] = i < KPT ? *reinterpret_cast<const uint4*>(key_src(t, i) + 2 * D + head * HD + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+        const int slot = hx_vt_slot(kq * 4);
+        const int sc = slot >> 3, eo = slot & 7;                 // eo is 0 or 4
+        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&v[0]);
+        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&v[1]);
+        const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&v[2]);
+        const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&v[3]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = c * 8 + e, dt = d >> 5, dl = d & 31;
+            const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+            uint2 w;
+            w.x = __builtin_amdgcn_perm(w1[e >> 1], w0[e >> 1], sel);
+            w.y = __builtin_amdgcn_perm(w3[e >> 1], w2[e >> 1], sel);
+            *reinterpret_cast<uint2*>(vt_lds + (t * NDT + dt) * 2048 + dl * 64 + ((sc ^ ((dl >> 2) & 3)) * 16) + eo * 2) = w;
         }
     }
     __syncthreads();

@@ -55,6 +55,13 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config):
         return []
     if float(r) != int(r) or not np.issubdtype(graph_points.dtype, np.integer):
         return [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
+    import time
+    prof = os.environ.get("SRH_PROFILE_HOST") == "1"
+    t_sec = [time.perf_counter()]
+    def lap(name):
+        if prof:
+            t_sec.append(time.perf_counter())
+            print(f"[queries] {name}: {(t_sec[-1] - t_sec[-2]) * 1e3:.1f} ms", flush=True)
     lib = _lib.load()
     pts = np.ascontiguousarray(graph_points, dtype=np.int64)
     boxes = np.ascontiguousarray([[*infos[t][1], *infos[t][2]] for t in range(lo, hi)], dtype=np.int32)
@@ -71,6 +78,7 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config):
     if lib.srh_pass2_fill(vp(pts), pts.shape[0], vp(boxes), n_tiles, k, int(r), vp(offsets), vp(ids), vp(knn), vp(amb),
                           max(1, min(16, (os.cpu_count() or 2) - 1))) != 0:
         raise _lib.SrhError("srh_pass2_fill failed")
+    lap("count + fill (library)")
     tile_of = np.repeat(np.arange(n_tiles), counts)
     src_local = np.arange(total, dtype=np.int64) - offsets[:-1][tile_of]
     valid = knn >= 0
@@ -78,21 +86,26 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config):
     local = pts[ids] - boxes[tile_of, :2].astype(np.int64)
     cut = offsets[1:-1]
     # ambiguous source points: the reference's own scipy query, on a kd-tree of their tile's points (rows overwritten in place)
+    lap("numpy post")
     amb_rows = np.nonzero(amb)[0]
     if amb_rows.size:
-        def requery(t):
+        # scipy.spatial.KDTree(pts) IS cKDTree(pts, leafsize=10, compact_nodes=True, balanced_tree=True) behind a Python
+        # wrapper (scipy/spatial/_kdtree.py); the C class is used directly here (same tree, same answers — pinned against the
+        # reference's own call by tests/test_host_logic.py) because ~150 tiles per scene need one.  Serial on purpose: the
+        # per-tile work is mostly interpreter time, a thread pool made it 3x slower.
+        for t in np.unique(tile_of[amb_rows]):
             a, b_ = int(offsets[t]), int(offsets[t + 1])
             rows = amb_rows[np.searchsorted(amb_rows, a):np.searchsorted(amb_rows, b_)]
-            tree = scipy.spatial.KDTree(local[a:b_])        # same class and defaults as the reference (leafsize decides ties)
+            tree = scipy.spatial.cKDTree(local[a:b_], leafsize=10)
             _, nn = tree.query(local[rows], k=k + 1, distance_upper_bound=r)
             nn = nn[:, 1:]
             ok = nn < (b_ - a)
-            valid[rows] = ok                                # disjoint rows per tile: the workers never touch the same entries
+            valid[rows] = ok
             pairs[rows, :, 1] = np.where(ok, nn, (rows - a)[:, None])
-        tiles = np.unique(tile_of[amb_rows])
-        # the kd-tree build and query release the GIL: tiles are re-queried concurrently
-        list(_pool().map(requery, tiles)) if len(tiles) > 4 else [requery(t) for t in tiles]
-    return list(zip(np.split(ids, cut), np.split(local, cut), np.split(pairs, cut), np.split(valid, cut)))
+    lap("tied re-queries")
+    out = list(zip(np.split(ids, cut), np.split(local, cut), np.split(pairs, cut), np.split(valid, cut)))
+    lap("split")
+    return out
 
 
 def _collate(xs):
@@ -104,27 +117,22 @@ def _collate(xs):
     return out
 
 
-_POOL = None
-
-
-def _pool():
-    """Worker threads for the per-tile query builder: the tiles are independent and scipy's cKDTree build / query
-    release the GIL, so the 256 small trees of a scene are built concurrently (results stay in tile order)."""
-    global _POOL
-    if _POOL is None:
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2) - 1)))
-    return _POOL
-
-
 def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
     """Pass 2 over tiles [lo, hi) whose embeddings are emb[0 : hi-lo] (inferencer.py:135-221): returns the
     unique directed edge keys (src * n_points + tgt) with their score sums and counts.  The sums are accumulated in
     float64 in the reference's order (tile, point, neighbour slot), so they are bit-identical to its dict loop."""
+    import os
+    import time
+    prof = os.environ.get("SRH_PROFILE_HOST") == "1"      # tuning aid: print the wall time of each section
+    t_sec = [time.perf_counter()]
+    def lap(name):
+        if prof:
+            t_sec.append(time.perf_counter())
+            print(f"[edge_votes] {name}: {(t_sec[-1] - t_sec[-2]) * 1e3:.1f} ms", flush=True)
     bs = int(config.INFER_BATCH_SIZE)
     n_pts = graph_points.shape[0]
     all_q = build_all_patch_queries(graph_points, infos, lo, hi, config)
+    lap("build_all_patch_queries")
     # launch every batch before fetching any scores.  Indices travel as int32 and the integer pixel coordinates as float32
     # (exact; srh_toponet accepts both, model.py:47's division promotes anyway).
     launched = []
@@ -140,6 +148,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
                                    torch.as_tensor(pairs).to(device, non_blocking=True),
                                    torch.as_tensor(valid).to(device, non_blocking=True))
         launched.append((qs, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
+    lap("collate + H2D + launch")
     keys_l, score_l = [], []
     for qs, scores_dev in launched:
         scores = scores_dev.cpu().numpy()
@@ -153,6 +162,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
             score_l.append(sc.astype(np.float64))
     if not keys_l:
         return np.zeros(0, np.int64), np.zeros(0), np.zeros(0)
+    lap("score fetch + keys")
     k = np.ascontiguousarray(np.concatenate(keys_l), dtype=np.int64)
     s = np.ascontiguousarray(np.concatenate(score_l), dtype=np.float64)
     # the reference's dict accumulation (float64 sums in visiting order) as a stable radix sort by key + one sequential pass
@@ -164,6 +174,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     if _lib.load().srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), C.byref(nu)) != 0:
         raise _lib.SrhError("srh_edge_vote_accumulate failed")
+    lap("accumulate")
     return uk[:nu.value], sums[:nu.value], cnts[:nu.value]
 
 

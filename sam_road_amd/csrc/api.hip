@@ -20,12 +20,16 @@ using namespace srh;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int ensure(size_t bytes) {
+    // grow-only; `slack` (a fraction of the request) is added when a buffer's size follows the data (the TopoNet
+    // workspaces scale with the number of graph points of a batch): hipFree + hipMalloc synchronise the device, so
+    // growing by a few rows per batch would cost milliseconds per call
+    int ensure(size_t bytes, double slack = 0.0) {
         if (bytes <= cap) return 0;
         if (p) hipFree(p);
         p = nullptr; cap = 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) return SRH_ERR_HIP;
-        cap = bytes;
+        const size_t want = bytes + (size_t)(bytes * slack);
+        if (hipMalloc(&p, want) != hipSuccess) return SRH_ERR_HIP;
+        cap = want;
         return 0;
     }
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
@@ -600,15 +604,17 @@ extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embedd
     hipStream_t s = (hipStream_t)stream;
     const size_t NP = (size_t)B * N, R = (size_t)B * Ns * K;
     int rc = 0;
-    rc |= c->t_feat16.ensure(NP * 256 * 2);
-    rc |= c->t_pf16.ensure(NP * 128 * 2);
-    rc |= c->t_pair16.ensure(R * 320 * 2);
-    rc |= c->t_x.ensure(R * 128 * 4);
-    rc |= c->t_x16.ensure(R * 128 * 2);
-    rc |= c->t_qkv16.ensure(R * 384 * 2);
-    rc |= c->t_at16.ensure(R * 128 * 2);
-    rc |= c->t_y.ensure(R * 128 * 4);
-    rc |= c->t_h16.ensure(R * 128 * 2);
+    rc |= c->t_feat16.ensure(NP * 256 * 2, 0.25);
+    rc |= c->t_pf16.ensure(NP * 128 * 2, 0.25);
+    rc |= c->t_pair16.ensure(R * 320 * 2, 0.25);
+    if (!topo_fused()) {        // activations of the layer-by-layer path (the fused trunk keeps them in registers)
+        rc |= c->t_x.ensure(R * 128 * 4, 0.25);
+        rc |= c->t_x16.ensure(R * 128 * 2, 0.25);
+        rc |= c->t_qkv16.ensure(R * 384 * 2, 0.25);
+        rc |= c->t_at16.ensure(R * 128 * 2, 0.25);
+        rc |= c->t_y.ensure(R * 128 * 4, 0.25);
+        rc |= c->t_h16.ensure(R * 128 * 2, 0.25);
+    }
     if (rc) return fail(c, SRH_ERR_HIP, "toponet workspace allocation failed");
 
     SampleParams sp;

@@ -774,7 +774,7 @@ int gemm_splitk_factor(const GemmParams& p) {
     if (tiles >= 224 || nk < 16) return 1;
     int s = (int)(512 / tiles);
     if (s > 4) s = 4;
-    while (s > 1 && nk / s < 6) --s;
+    while (s > 1 && nk / s < 12) --s;          // a slice shorter than 12 k-tiles does not pay for the reduce pass (ViT-H proj: K = 1280)
     return s;
 }
 

@@ -568,6 +568,15 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         g1.A = c->d0_16.as<f16>(); g1.lda = 128; g1.W = w->dec3_w; g1.ldw = 128; g1.M = 4 * T; g1.N = 256; g1.K = 128;
         g1.bias = w->dec3_b; g1.act = 1; g1.out_f16 = c->d1_16.as<f16>(); g1.ldc16 = 256;
         TRY(gemm(c, "gemm_decoder", g1, s));
+        static const bool tail_fused = !(getenv("SRH_DECODE_FUSED") && atoi(getenv("SRH_DECODE_FUSED")) == 0);
+        if (tail_fused) {       // ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + scatter in one register-resident kernel
+            DecodeTailParams tp;
+            tp.x = c->d1_16.as<f16>(); tp.w5 = w->dec5_w; tp.b5 = w->dec5_b; tp.w7 = w->dec7_w; tp.b7 = w->dec7_b;
+            tp.B = B; tp.S = S; tp.logits = logits; tp.scores = scores;
+            TRYK(c, "decode_tail", 2.0 * T * 16 * (64 * 128 + 4 * 32 * 8), (double)T * 16 * 128 + (double)T * 64 * ((logits ? 32 : 0) + (scores ? 32 : 0)), s,
+                 launch_decode_tail(tp, s));
+            return 0;
+        }
         GemmParams g2;
         g2.A = c->d1_16.as<f16>(); g2.lda = 64; g2.W = w->dec5_w; g2.ldw = 64; g2.M = 16 * T; g2.N = 128; g2.K = 64;
         g2.bias = w->dec5_b; g2.act = 1; g2.out_f16 = c->d2_16.as<f16>(); g2.ldc16 = 128;

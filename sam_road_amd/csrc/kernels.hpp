@@ -97,6 +97,19 @@ struct DecodeOutParams {
 };
 int launch_decode_out(const DecodeOutParams& p, hipStream_t s);
 
+// last two decoder layers fused (decoder.hip decode_tail_kernel): ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + NHWC scatter
+struct DecodeTailParams {
+    const f16* x = nullptr;      // [B*S*S*16, 64] rows in quad-tree order (px, sub1, sub2): the dec3 GEMM's output
+    const f16* w5 = nullptr;     // [128, 64]: n = sub3 * 32 + co
+    const float* b5 = nullptr;   // [128]
+    const float* w7 = nullptr;   // [8, 32]: n = (ky*2+kx)*2 + class
+    const float* b7 = nullptr;   // [2]
+    int B = 0, S = 0;
+    float* logits = nullptr;     // nullable [B,P,P,2]
+    float* scores = nullptr;     // nullable [B,P,P,2]
+};
+int launch_decode_tail(const DecodeTailParams& p, hipStream_t s);
+
 // Scene canvases -> u8 masks (divide by analytic coverage count, x255, truncate; uncovered -> 0).
 struct SceneNormParams {
     const float* canvas_kp = nullptr; const float* canvas_road = nullptr;

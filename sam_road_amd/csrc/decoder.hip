@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(DecodeTailParams p) {
                 const float4 lg = make_float4(o[0] + b7a, o[1] + b7b, o[2] + b7a, o[3] + b7b);
                 if (p.logits) *reinterpret_cast<float4*>(p.logits + off) = lg;
                 if (p.scores) {
-                    const float4 sc = make_float4(1.f / (1.f + expf(-lg.x)), 1.f / (1.f + expf(-lg.y)),
-                                                  1.f / (1.f + expf(-lg.z)), 1.f / (1.f + expf(-lg.w)));
-                    *reinterpret_cast<float4*>(p.scores + off) = sc;
+                    // sigmoid as rcp(1 + exp2(-x log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~25-instruction
+                    // expf + IEEE division sequence — the kernel is VALU-bound (32 GELUs + 16 sigmoids per lane and tile)
+                    auto sg = [](float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); };
+                    *reinterpret_cast<float4*>(p.scores + off) = make_float4(sg(lg.x), sg(lg.y), sg(lg.z), sg(lg.w));
                 }
             }
         }

@@ -2,64 +2,57 @@
 //
 // Reference: inferencer.py:52-58 (python crop + f32 stack + H2D), model.py:465-467
 // ((x - mean) / std, NHWC -> NCHW) and the fork's PatchEmbed Conv2d(3, D, 16, 16).
-// Here the crop, the normalisation and the im2col are one pass: each thread owns one patch row
-// (16 px x 3 ch = 48 contiguous values of the channels-last source) and writes 48 contiguous
-// fp16 of the GEMM A matrix, whose K axis is ordered (ky, kx, c) — the conv weight is permuted
-// to match at pack time.  HBM-bound: 48 B (u8 scene) or 192 B (f32 tiles) in, 96 B out per thread.
+// Here the crop, the normalisation and the im2col are one pass over the channels-last source into the
+// GEMM A matrix, whose K axis is ordered (ky, kx, c) — the conv weight is permuted to match at pack
+// time.  HBM-bound: 1 B (u8 scene) or 4 B (f32 tiles) in, 2 B out per value.
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace srh {
 
+// One thread = 4 consecutive values of one image row (the row of a tile is P*3 contiguous values: consecutive lanes read
+// consecutive 16-byte (f32) / 4-byte (u8) pieces — fully coalesced; the first version gave each thread a whole 48-value
+// patch row, i.e. 64 lanes read 64 different image rows per load instruction).  48 = 16 px * 3 is a multiple of 4, so a
+// thread's 4 values never straddle two patches and land as one 8-byte store in the im2col row (k = ky*48 + kx*3 + c).
 template <bool U8>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(PatchParams p) {
-    const int S = p.P / 16;
-    const long total = (long)p.B * S * S * 16;
+    const int S = p.P / 16, Q = p.P * 3 / 4;               // 4-value pieces per tile row
+    const long total = (long)p.B * p.P * Q;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
-    const int ky = gid & 15;
-    const long m = gid >> 4;
-    const int px = m % S, py = (m / S) % S, b = m / ((long)S * S);
-    long row_stride, base;
+    const int q = (int)(gid % Q);
+    const int y = (int)((gid / Q) % p.P);
+    const int b = (int)(gid / ((long)Q * p.P));
+    long src_off;
     if (p.scene_S > 0) {
         const int x0 = p.tile_xy[2 * b], y0 = p.tile_xy[2 * b + 1];
-        row_stride = (long)p.scene_S * 3;
-        base = (long)(y0 + py * 16 + ky) * row_stride + (long)(x0 + px * 16) * 3;
+        src_off = ((long)(y0 + y) * p.scene_S + x0) * 3 + 4 * q;
     } else {
-        row_stride = (long)p.P * 3;
-        base = (long)b * p.P * row_stride + (long)(py * 16 + ky) * row_stride + (long)px * 48;
+        src_off = ((long)b * p.P + y) * p.P * 3 + 4 * q;
     }
-    const float mean[3] = {123.675f, 116.28f, 103.53f};
-    const float stdv[3] = {58.395f, 57.12f, 57.375f};
-    f16* out = p.out + m * 768 + ky * 48;
-    float v[48];
+    float v[4];
     if (U8) {
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(p.src) + base;
-#pragma unroll
-        for (int i = 0; i < 48; ++i) v[i] = (float)src[i];
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(p.src) + src_off;   // scene rows need not be 4-byte aligned
+        v[0] = (float)src[0]; v[1] = (float)src[1]; v[2] = (float)src[2]; v[3] = (float)src[3];
     } else {
-        const float* src = reinterpret_cast<const float*>(p.src) + base;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(src + 4 * i);
-            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-        }
+        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.src) + src_off);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    // (x - mean) / std (model.py:465-467) as a multiply by the f32 reciprocal: within 1 ulp of the division before the
+    // result is rounded to fp16 anyway
+    const float mean[3] = {123.675f, 116.28f, 103.53f};
+    const float rstd[3] = {1.0f / 58.395f, 1.0f / 57.12f, 1.0f / 57.375f};
+    const int e0 = 4 * q;                                   // element index in the tile row: px*48 + kx*3 + c
+    const int px = e0 / 48, within = e0 % 48;
+    f16x4 h;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        f16x8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = i * 8 + e, c = k % 3;
-            h[e] = (f16)((v[k] - mean[c]) / stdv[c]);
-        }
-        *reinterpret_cast<f16x8*>(out + i * 8) = h;
-    }
+    for (int e = 0; e < 4; ++e) { const int c = (within + e) % 3; h[e] = (f16)((v[e] - mean[c]) * rstd[c]); }
+    const long m = ((long)b * S + (y >> 4)) * S + px;
+    *reinterpret_cast<f16x4*>(p.out + m * 768 + (y & 15) * 48 + within) = h;
 }
 
 int launch_patch_im2col(const PatchParams& p, hipStream_t s) {
-    const int S = p.P / 16;
-    const long total = (long)p.B * S * S * 16;
+    const long total = (long)p.B * p.P * (p.P * 3 / 4);
     if (total <= 0) return 0;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (p.src_is_u8) hipLaunchKernelGGL(patch_im2col_kernel<true>, grid, block, 0, s, p);

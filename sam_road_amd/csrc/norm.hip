@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
             }
         }
     }
+    const float inv_d = 1.0f / (float)p.D;   // once per wave: an IEEE division per row statistic costs ~20 VALU instructions
     for (int row0 = wave_global * R; row0 < p.M; row0 += n_waves * R) {
         float v[R][EPL];
         f16 dl[R][EPL];                                   // optional fp16 residual-branch output to fold in (dead when unused)
@@ -86,11 +87,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) s += v[r][e];
-                const float mean = wave_sum(s) / (float)p.D;
+                const float mean = wave_sum(s) * inv_d;
                 float q = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { v[r][e] -= mean; q += v[r][e] * v[r][e]; }
-                const float rstd = rsqrtf(wave_sum(q) / (float)p.D + p.eps);
+                const float rstd = rsqrtf(wave_sum(q) * inv_d + p.eps);
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     float y = v[r][e] * rstd * g[e] + be[e];

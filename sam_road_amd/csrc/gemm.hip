@@ -813,7 +813,11 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     // count fills the chip evenly (<= one round, or >= 80 % occupancy of the last round), else 128x128.
     const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
     const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
-    if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && (fits256 || variant >= 20)) {
+    // short-K layers (decoder ConvT: K = 128 / 256) are all prologue + epilogue: two 128x128 workgroups per CU overlap each
+    // other's store tail, one 256x256 workgroup cannot (SRH_GEMM_SHORTK256=1 restores the old choice)
+    static const bool shortk256 = getenv("SRH_GEMM_SHORTK256") && atoi(getenv("SRH_GEMM_SHORTK256")) == 1;
+    const bool short_k = p.K <= 256 && !shortk256 && variant < 20;
+    if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && !short_k && (fits256 || variant >= 20)) {
         const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
         if (variant == 30 && p.K >= 128) {   // experimental ring pipeline: measured no faster than the 2-stage kernel
             hipLaunchKernelGGL(gemm_ring256_kernel, g256, dim3(512), 131072, stream, p);

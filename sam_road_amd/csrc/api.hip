@@ -121,6 +121,12 @@ static bool topo_fused() {
     return v;
 }
 
+// SRH_DECODE_FUSED=0 selects the layer-by-layer decoder tail (dec5 GEMM + decode_out_kernel)
+static bool decode_fused() {
+    static const bool v = !(getenv("SRH_DECODE_FUSED") && atoi(getenv("SRH_DECODE_FUSED")) == 0);
+    return v;
+}
+
 static bool attn_fused() {
     static const bool v = !(getenv("SRH_ATTN_FUSED") && atoi(getenv("SRH_ATTN_FUSED")) == 0);
     return v;
@@ -449,7 +455,7 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
     rc |= c->xn16.ensure(T * D * 2);
     rc |= c->delta16.ensure(T * D * 2);
     rc |= c->qkv16.ensure(T * 3 * D * 2);
-    rc |= c->rel.ensure(T * w->heads * 64 * 4);
+    if (!attn_fused()) rc |= c->rel.ensure(T * w->heads * 64 * 4);      // separate rel-pos pass only
     rc |= c->attn16.ensure(T * D * 2);
     rc |= c->hid16.ensure(T * 4 * D * 2);
     rc |= c->n1.ensure(T * 256 * 4);
@@ -459,7 +465,7 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
     rc |= c->d0.ensure(T * 512 * 4);
     rc |= c->d0_16.ensure(T * 512 * 2);
     rc |= c->d1_16.ensure(T * 1024 * 2);
-    rc |= c->d2_16.ensure(T * 2048 * 2);
+    if (!decode_fused()) rc |= c->d2_16.ensure(T * 2048 * 2);            // the fused tail keeps this level in registers
     return rc ? fail(c, SRH_ERR_HIP, "workspace allocation failed") : 0;
 }
 
@@ -568,8 +574,7 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         g1.A = c->d0_16.as<f16>(); g1.lda = 128; g1.W = w->dec3_w; g1.ldw = 128; g1.M = 4 * T; g1.N = 256; g1.K = 128;
         g1.bias = w->dec3_b; g1.act = 1; g1.out_f16 = c->d1_16.as<f16>(); g1.ldc16 = 256;
         TRY(gemm(c, "gemm_decoder", g1, s));
-        static const bool tail_fused = !(getenv("SRH_DECODE_FUSED") && atoi(getenv("SRH_DECODE_FUSED")) == 0);
-        if (tail_fused) {       // ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + scatter in one register-resident kernel
+        if (decode_fused()) {       // ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + scatter in one register-resident kernel
             DecodeTailParams tp;
             tp.x = c->d1_16.as<f16>(); tp.w5 = w->dec5_w; tp.b5 = w->dec5_b; tp.w7 = w->dec7_w; tp.b7 = w->dec7_b;
             tp.B = B; tp.S = S; tp.logits = logits; tp.scores = scores;

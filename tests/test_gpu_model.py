@@ -124,6 +124,27 @@ def test_toponet_golden_through_hip(golden_dir):
     assert np.isfinite(ts.numpy()).all()
 
 
+@pytest.mark.parametrize("version", ["no_offset", "no_transformer", "no_tgt_features"])
+def test_toponet_variants_golden_through_hip(golden_dir, version):
+    """The other TOPONET_VERSIONs: outputs of the REFERENCE's own source (golden fixture) vs the HIP path."""
+    from conftest import load_golden_module
+    mg = load_golden_module()
+    g = np.load(f"{golden_dir}/toponet_sampler.npz")
+    gv = np.load(f"{golden_dir}/toponet_variants.npz")
+    oracle, net = build_pair(CFG512 | dict(ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[], TOPONET_VERSION=version))
+    sd = net.state_dict()
+    for k, v in mg.topo_weights(oracle.topo_net.state_dict()).items():
+        sd["topo_net." + k] = v
+    net.load_state_dict(sd, strict=True)
+    net.to("cuda")
+    points, pairs, valid = (torch.tensor(g[k]) for k in ("points", "pairs", "valid"))
+    ts = net.infer_toponet(mg.topo_feats().cuda(), points.cuda(), pairs.cuda(), valid.cuda()).cpu()
+    v = valid.numpy().astype(bool)
+    err = np.abs(ts.numpy()[..., 0][v] - gv[version + "_scores"][..., 0][v]).max()
+    print(version, "vs reference-source golden: max abs", err)
+    assert err < 2e-2 and np.isfinite(ts.numpy()).all()
+
+
 def test_u8_and_f32_inputs_agree():
     _, net = build_pair(CFG512 | dict(ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[]))
     rgb = synth_tiles(1, 512, seed=4)

@@ -2,6 +2,7 @@
 reference's own source (TopoNet, BilinearSampler, get_patch_info_one_img, nms_points —
 extracted by AST in tests/golden/make_golden.py) and of the independent HF SAM encoder."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden_module
@@ -25,6 +26,26 @@ def test_toponet_and_sampler_match_reference_source(golden_dir):
     v = valid.numpy().astype(bool)
     np.testing.assert_allclose(logits.numpy()[..., 0][v], g["logits"][..., 0][v], atol=2e-5)
     np.testing.assert_allclose(scores.numpy()[..., 0][v], g["scores"][..., 0][v], atol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["no_offset", "no_transformer", "no_tgt_features"])
+def test_toponet_variants_match_reference_source(golden_dir, version):
+    """The oracle's TopoNet for the other TOPONET_VERSIONs against the reference SOURCE executed on the same inputs
+    ('no_tgt_features' is overwritten by the reference's if/else chain and equals 'normal')."""
+    g = np.load(f"{golden_dir}/toponet_sampler.npz")
+    gv = np.load(f"{golden_dir}/toponet_variants.npz")
+    mg = load_golden_module()
+    cfg = AttrDict(PATCH_SIZE=512, TOPONET_VERSION=version)
+    topo = TopoNet(cfg, 256).eval()
+    topo.load_state_dict(mg.topo_weights(topo.state_dict()), strict=True)
+    points, pairs, valid = (torch.tensor(g[k]) for k in ("points", "pairs", "valid"))
+    with torch.no_grad():
+        logits, scores = topo(points, torch.tensor(g["sampled"]), pairs, valid)
+    v = valid.numpy().astype(bool)
+    np.testing.assert_allclose(logits.numpy()[..., 0][v], gv[version + "_logits"][..., 0][v], atol=2e-5)
+    np.testing.assert_allclose(scores.numpy()[..., 0][v], gv[version + "_scores"][..., 0][v], atol=1e-5)
+    if version == "no_tgt_features":
+        np.testing.assert_allclose(gv[version + "_logits"][..., 0][v], g["logits"][..., 0][v], atol=1e-6)
 
 
 def test_patch_info_matches_reference_source(golden_dir):

@@ -48,6 +48,23 @@ def test_toponet_variants_match_reference_source(golden_dir, version):
         np.testing.assert_allclose(gv[version + "_logits"][..., 0][v], g["logits"][..., 0][v], atol=1e-6)
 
 
+def test_sat2graph_format_matches_reference_source(golden_dir):
+    """sam_road_amd.formats against the reference SOURCE (graph_utils.py:383-434) on seeded random graphs: same dict
+    (key order, neighbour order) and the same round trip."""
+    from sam_road_amd.formats import convert_from_sat2graph_format, convert_to_sat2graph_format
+    g = np.load(f"{golden_dir}/sat2graph_format.npz")
+    for i in range(3):
+        got = convert_to_sat2graph_format(g[f"nodes{i}"], g[f"edges{i}"])
+        keys = [tuple(k) for k in g[f"keys{i}"].tolist()]
+        assert list(got.keys()) == keys
+        flat = [tuple(p) for v in got.values() for p in v]
+        assert [len(v) for v in got.values()] == g[f"lens{i}"].tolist()
+        assert flat == [tuple(p) for p in g[f"nbrs{i}"].tolist()]
+        n2, e2 = convert_from_sat2graph_format(got)
+        np.testing.assert_array_equal(np.asarray(n2, dtype=np.int64).reshape(-1, 2), g[f"rt_nodes{i}"])
+        np.testing.assert_array_equal(np.asarray(e2, dtype=np.int64).reshape(-1, 2), g[f"rt_edges{i}"])
+
+
 def test_patch_info_matches_reference_source(golden_dir):
     g = np.load(f"{golden_dir}/patch_info.npz")
     i = 0

@@ -48,6 +48,21 @@ def test_toponet_variants_match_reference_source(golden_dir, version):
         np.testing.assert_allclose(gv[version + "_logits"][..., 0][v], g["logits"][..., 0][v], atol=1e-6)
 
 
+def test_extract_graph_points_matches_reference_source(golden_dir):
+    """mask -> graph points: the product's host stage (library mask scan + grid NMS, sam_road_amd/graph_points.py) and the
+    oracle's restatement against the reference SOURCE (graph_extraction.py:130-139) — same points in the same order."""
+    from sam_road_amd import Config
+    from sam_road_amd.graph_points import extract_graph_points
+    g = np.load(f"{golden_dir}/graph_points.npz")
+    for i in range(3):
+        itsc, road, r0, r1 = g[f"cfg{i}"].tolist()
+        kw = dict(ITSC_THRESHOLD=itsc, ROAD_THRESHOLD=road, ITSC_NMS_RADIUS=int(r0), ROAD_NMS_RADIUS=int(r1))
+        want = g[f"pts{i}"]
+        assert want.shape[0] > 5
+        np.testing.assert_array_equal(extract_graph_points(g[f"kp{i}"], g[f"road{i}"], Config(**kw)), want)
+        np.testing.assert_array_equal(scene.extract_graph_points(g[f"kp{i}"], g[f"road{i}"], AttrDict(kw)), want)
+
+
 def test_sat2graph_format_matches_reference_source(golden_dir):
     """sam_road_amd.formats against the reference SOURCE (graph_utils.py:383-434) on seeded random graphs: same dict
     (key order, neighbour order) and the same round trip."""

@@ -230,19 +230,26 @@ extern "C" int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, fl
     int first = 256;                      // smallest u8 value that passes
     for (int v = 255; v >= 0; --v) { if ((float)v > threshold) first = v; else break; }
     int64_t c = 0;
-    if (!xy) {
-        const size_t total = (size_t)H * (size_t)W;
-        for (size_t i = 0; i < total; ++i) c += mask[i] >= first;
-        *n = first > 255 ? 0 : c;
-        return 0;
-    }
-    if (first <= 255) {
-        for (int32_t y = 0; y < H; ++y) {
-            const uint8_t* row = mask + (size_t)y * W;
-            for (int32_t x = 0; x < W; ++x) {
-                if (row[x] >= first) {
-                    if (c >= capacity) return SRH_ERR_BAD_ARG;
-                    xy[2 * c] = x; xy[2 * c + 1] = y; scores[c] = row[x];
+    if (first > 255) { *n = 0; return 0; }
+    const uint8_t f8 = (uint8_t)first;
+    // masks are sparse (a few % of the pixels pass): test 64-byte chunks with a byte-max reduction (vectorises to pmaxub)
+    // and look at single pixels only inside chunks that contain a candidate
+    auto chunk_has = [f8](const uint8_t* q, int len) {
+        uint8_t m = 0;
+        for (int i = 0; i < len; ++i) m = q[i] > m ? q[i] : m;
+        return m >= f8;
+    };
+    for (int32_t y = 0; y < H; ++y) {
+        const uint8_t* row = mask + (size_t)y * W;
+        for (int32_t x0 = 0; x0 < W; x0 += 64) {
+            const int len = std::min(64, W - x0);
+            if (!chunk_has(row + x0, len)) continue;
+            for (int32_t x = x0; x < x0 + len; ++x) {
+                if (row[x] >= f8) {
+                    if (xy) {
+                        if (c >= capacity) return SRH_ERR_BAD_ARG;
+                        xy[2 * c] = x; xy[2 * c + 1] = y; scores[c] = row[x];
+                    }
                     ++c;
                 }
             }

@@ -91,7 +91,7 @@ def gather_edge_votes(keys, sums, counts, n_points, dst=0, device=None):
     allp = np.concatenate(parts, axis=0) if parts else np.zeros((0, 3))
     k = allp[:, 0].astype(np.int64)
     uk, inv = np.unique(k, return_inverse=True)
-    s = np.zeros(uk.shape[0]); c = np.zeros(uk.shape[0])
-    np.add.at(s, inv, allp[:, 1])
-    np.add.at(c, inv, allp[:, 2])
+    # np.bincount adds in array order (rank-major, each rank's keys ascending): the same order np.add.at used, ~50x faster
+    s = np.bincount(inv, weights=allp[:, 1], minlength=uk.shape[0])
+    c = np.bincount(inv, weights=allp[:, 2], minlength=uk.shape[0])
     return uk, s, c

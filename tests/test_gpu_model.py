@@ -46,7 +46,7 @@ CFG_H256 = dict(SAM_VERSION="vit_h", PATCH_SIZE=256, TOPONET_VERSION="normal", S
     (CFG512, 1, 1, [0]),       # one global block
     (CFG256, 2, 2, [1]),       # 256 tile: windowed + global(16)
     (CFG_L256, 1, 2, [1]),     # ViT-L: D = 1024, 16 heads x 64
-    (CFG_H256, 2, 2, [1]),     # ViT-H: D = 1280, 16 heads x 80 (generic attention kernel)
+    (CFG_H256, 2, 2, [1]),     # ViT-H: D = 1280, 16 heads x 80 (attention_hdx.hip MFMA kernels; split-K GEMMs)
     (dict(CFG512, PATCH_SIZE=1024), 1, 2, [1]),   # toponet_vitb_1024.yaml: 5x5 windows + 64x64 global window
     (CFG512, 8, 2, [1]),       # 8192 tokens: the persistent q192 GEMM + residual-add-in-LayerNorm path is taken
 ])

@@ -127,8 +127,13 @@ class ImageEncoderViT(nn.Module):
     """Same constructor meaning as the call at reference ``model.py:245-258``."""
 
     def __init__(self, img_size, embed_dim, depth, num_heads, global_attn_indexes,
-                 patch_size=16, window_size=14, out_chans=256, eps=1e-6):
+                 patch_size=16, window_size=14, out_chans=256, eps=1e-6,
+                 mlp_ratio=4, norm_layer=None, qkv_bias=True, use_rel_pos=True):
         super().__init__()
+        # the remaining keyword arguments of the call at model.py:245-258; only the values the reference passes exist here
+        assert mlp_ratio == 4 and qkv_bias and use_rel_pos
+        if norm_layer is not None:
+            eps = norm_layer(1).eps
         self.img_size = img_size
         grid = img_size // patch_size
         self.patch_embed = _PatchEmbed(embed_dim, patch_size)

@@ -39,6 +39,33 @@ def synth_state_dict(model, seed=1234):
     return sd
 
 
+def synth_state_dict_keyed(model, seed=1234):
+    """Like synth_state_dict, but every tensor is drawn from its own generator seeded by (seed, crc32(key)), so the values do
+    not depend on the order in which a module tree registers its parameters (the reference's LoRA surgery, model.py:303-347,
+    re-registers qkv inside a wrapper).  LoRA B matrices (zero-initialised by the reference) are made non-zero."""
+    import zlib
+    sd = {}
+    for k, v in model.state_dict().items():
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(k.encode())) % (2 ** 31))
+        shape = tuple(v.shape)
+        if k.endswith(".weight") and v.dim() == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif k.endswith(".bias") or k.endswith("in_proj_bias") or "rel_pos" in k or k.endswith("pos_embed"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif ".linear_b_" in k or ".linear_a_" in k:
+            t = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = int(np.prod(shape[1:])) if v.dim() > 1 else shape[0]
+            if "map_decoder" in k and v.dim() == 4:
+                fan_in = shape[0]
+            std = 0.02 if k.startswith("image_encoder") else 1.0 / np.sqrt(fan_in)
+            t = (std * torch.randn(shape, generator=g)).clamp_(-2 * std, 2 * std)
+        sd[k] = t.to(v.dtype)
+    if "map_decoder.7.bias" in sd:
+        sd["map_decoder.7.bias"] = torch.full_like(sd["map_decoder.7.bias"], -3.0)
+    return sd
+
+
 def synth_tiles(batch, patch, seed=0):
     """[B,P,P,3] float32 with u8 values: uniform noise low-pass filtered with an
     8-px box so LayerNorm statistics are image-like."""

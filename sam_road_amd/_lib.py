@@ -82,7 +82,9 @@ def load():
 
 
 class Context:
-    """One per (process, device)."""
+    """One per (process, device).  A context is SINGLE-STREAM: its workspaces (activations, split-K partials, TopoNet
+    scratch) are shared by every call, so calls on the same context must be issued on one HIP stream at a time (the
+    reference is single-threaded on the default stream too, inferencer.py:93,200); use one process per GPU for more."""
     _by_device = {}
 
     def __init__(self, device_index):

@@ -5,6 +5,8 @@ import yaml
 
 class Config(dict):
     def __getattr__(self, k):
+        if k.startswith("__"):                 # copy / pickle / deepcopy protocol probes must see "no such attribute"
+            raise AttributeError(k)
         try:
             return self[k]
         except KeyError:

@@ -180,7 +180,14 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
 
 def infer_one_img(net, img, config, device=None):
     device = torch.device(device) if device is not None else next(net.parameters()).device
+    img = np.asarray(img)
+    # the reference uses img.shape[0] for both axes (inferencer.py:63,67) and casts whatever it gets to f32; a non-square or
+    # non-u8 scene would silently produce garbage here (row stride = S on the device), so it is refused instead
+    if img.ndim != 3 or img.shape[2] != 3 or img.shape[0] != img.shape[1] or img.dtype != np.uint8:
+        raise ValueError(f"infer_one_img expects a square HxWx3 uint8 scene, got {img.dtype} {tuple(img.shape)}")
     image_size = img.shape[0]
+    if image_size < int(config.PATCH_SIZE) + 2 * int(config.SAMPLE_MARGIN or 0):
+        raise ValueError(f"scene {image_size} px is smaller than PATCH_SIZE + 2 * SAMPLE_MARGIN")
     bs = int(config.INFER_BATCH_SIZE)
     infos = get_patch_info_one_img(0, image_size, config.SAMPLE_MARGIN, config.PATCH_SIZE,
                                    config.INFER_PATCHES_PER_EDGE)
@@ -192,7 +199,8 @@ def infer_one_img(net, img, config, device=None):
     # ---- pass 1 (GPU): crop -> encoder -> decoder -> fused canvases; embeddings stay resident
     scene = torch.as_tensor(np.ascontiguousarray(img), dtype=torch.uint8).to(device)
     xy_dev = torch.as_tensor(all_xy).to(device)
-    kp_c, road_c, emb = net.scene_pass1(scene, xy_dev[lo:hi], bs)
+    assert all_xy.min() >= 0 and all_xy.max() + int(config.PATCH_SIZE) <= image_size
+    kp_c, road_c, emb = net.scene_pass1(scene, xy_dev[lo:hi], bs)      # an empty shard (world > n_tiles) returns zero canvases
     D.reduce_canvases(kp_c, road_c, dst=0)
     graph_points = None
     kp_mask = road_mask = None

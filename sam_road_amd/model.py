@@ -136,8 +136,13 @@ class SAMRoad(nn.Module):
             nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2), nn.GELU(),
             nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2), nn.GELU(),
             nn.ConvTranspose2d(32, 2, kernel_size=2, stride=2))
-        self.topo_net = _TopoNetParams(config.TOPONET_VERSION)
+        # a YAML without TOPONET_VERSION (toponet_vith_256 / vitl_256 / vitb_256 / vitb_1024) yields an empty Config here; the
+        # reference then takes every `!=` / `==` string comparison's "normal" branch (model.py:84,111-116)
+        v = config.TOPONET_VERSION
+        self._topo_version = v if isinstance(v, str) else "normal"
+        self.topo_net = _TopoNetParams(self._topo_version)
         self._packed = {}  # device index -> (Context, weights handle)
+        self._packed_stamp = -1
         self._init_from_sam_checkpoint()
 
     # ---- init-time SAM checkpoint (model.py:365-411) ------------------------------------------------------
@@ -191,6 +196,12 @@ class SAMRoad(nn.Module):
         if device.type != "cuda":
             raise _lib.SrhError("SAMRoad runs on an MI355X only (tensor is on %s); there is no CPU fallback" % device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        # in-place parameter edits (p.data.copy_, an optimizer step, a manual LoRA merge, load_state_dict on a submodule) bump
+        # the tensors' version counters: the packed fp16 copy is rebuilt instead of silently serving stale weights
+        stamp = sum(p._version for p in self.parameters())
+        if stamp != self._packed_stamp:
+            self._invalidate()
+            self._packed_stamp = stamp
         hit = self._packed.get(idx)
         if hit is not None:
             return hit
@@ -212,7 +223,7 @@ class SAMRoad(nn.Module):
         for i, g in enumerate(gi):
             cfg.global_attn_indexes[i] = g
         cfg.window_size = 14
-        cfg.toponet_version = {"no_offset": 1, "no_transformer": 2}.get(self.config.TOPONET_VERSION, 0)
+        cfg.toponet_version = {"no_offset": 1, "no_transformer": 2}.get(self._topo_version, 0)
         names = [k for k in sd if ".linear_" not in k]
         arr = (_lib.NamedTensor * len(names))()
         keep = []
@@ -313,10 +324,14 @@ class SAMRoad(nn.Module):
         scene_u8 = scene_u8.contiguous()
         tile_xy = tile_xy.to(device=dev, dtype=torch.int32).contiguous()
         S, n, h = scene_u8.shape[0], tile_xy.shape[0], self.image_size // 16
+        if scene_u8.shape[1] != S:
+            raise ValueError(f"scene must be square, got {tuple(scene_u8.shape)}")
         if canvas_kp is None:
             canvas_kp = torch.zeros((S, S), dtype=torch.float32, device=dev)
             canvas_road = torch.zeros((S, S), dtype=torch.float32, device=dev)
         emb = torch.empty((n, h, h, 256), dtype=torch.float32, device=dev)
+        if n == 0:                                   # a rank without tiles (world_size > tile count): nothing to add
+            return canvas_kp, canvas_road, emb.permute(0, 3, 1, 2)
         with torch.cuda.device(dev):
             ctx.check(ctx.lib.srh_scene_pass1(ctx.handle, wh, scene_u8.data_ptr(), S, tile_xy.data_ptr(), n,
                                               int(batch_size), canvas_kp.data_ptr(), canvas_road.data_ptr(),

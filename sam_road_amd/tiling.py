@@ -14,5 +14,5 @@ def get_patch_info_one_img(image_index, image_size, sample_margin, patch_size, p
 def shard_tiles(n_tiles, world_size, rank):
     """Contiguous chunk of the tile list owned by `rank` (x-outer order makes each chunk a
     band of column strips).  Returns (begin, end)."""
-    per = (n_tiles + world_size - 1) // world_size
-    return min(rank * per, n_tiles), min((rank + 1) * per, n_tiles)
+    # balanced: chunk sizes differ by at most one and no rank is empty whenever n_tiles >= world_size
+    return n_tiles * rank // world_size, n_tiles * (rank + 1) // world_size

@@ -165,9 +165,10 @@ int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float thresho
 /* Directed edge votes of pass 2 (reference inferencer.py:209-221: dict of score sums / counts keyed by (src, tgt), filled in
  * tile / point / slot order).  keys[i] = src * n_points + tgt, scores[i] in that visiting order.  Writes the unique keys in
  * ascending order with their float64 sums — accumulated in the reference's order, hence bit-identical to its loop — and
- * counts; out arrays have capacity n. */
+ * counts; out_first (nullable) receives the index i of each key's first vote, i.e. its insertion position in the reference's
+ * dict, which fixes the order of the pred_edges list (inferencer.py:224-228); out arrays have capacity n. */
 int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys, double* out_sums,
-                             double* out_counts, int64_t* n_unique);
+                             double* out_counts, int64_t* out_first, int64_t* n_unique);
 
 #ifdef __cplusplus
 }

@@ -176,7 +176,7 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
 // scratch: caller-provided, 2 * n int64 + n uint32 is NOT needed — the function allocates its own temporaries.
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
-                                        double* out_sums, double* out_counts, int64_t* n_unique) {
+                                        double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique) {
     if (n < 0 || !n_unique || (n > 0 && (!keys || !scores || !out_keys || !out_sums || !out_counts))) return SRH_ERR_BAD_ARG;
     *n_unique = 0;
     if (n == 0) return 0;
@@ -210,7 +210,8 @@ extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* score
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t j = idx[(size_t)i];
         const int64_t k = kcur[(size_t)i];
-        if (k != prev) { ++u; out_keys[u] = k; out_sums[u] = 0.0; out_counts[u] = 0.0; prev = k; }
+        // the sort is stable: the first vote of a run is the key's first visit = its insertion position in the reference's dict
+        if (k != prev) { ++u; out_keys[u] = k; out_sums[u] = 0.0; out_counts[u] = 0.0; if (out_first) out_first[u] = j; prev = k; }
         out_sums[u] += scores[j];
         out_counts[u] += 1.0;
     }

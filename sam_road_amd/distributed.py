@@ -67,31 +67,38 @@ def broadcast_points(points, src=0, device=None):
     return buf.cpu().numpy()
 
 
-def gather_edge_votes(keys, sums, counts, n_points, dst=0, device=None):
-    """Each rank holds unique directed edge keys (src * n_points + tgt, int64) with f64 score sums and
-    counts.  Returns the merged (keys, sums, counts) on `dst`, (None, None, None) elsewhere."""
+def gather_edge_votes(keys, sums, counts, n_points, dst=0, device=None, first=None):
+    """Each rank holds unique directed edge keys (src * n_points + tgt, int64) with f64 score sums, counts and (optionally)
+    the local position of each key's first vote.  Returns the merged (keys, sums, counts, first) on `dst`, Nones elsewhere;
+    merged `first` orders keys as one process would have first seen them (ranks own consecutive tile chunks, so the global
+    visiting order is rank-major)."""
+    if first is None:
+        first = np.zeros(keys.shape[0], dtype=np.int64)
     if not is_distributed():
-        return keys, sums, counts
+        return keys, sums, counts, first
     dev = device if device is not None else torch.device("cpu")
     world, rank = dist.get_world_size(), dist.get_rank()
     n_local = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
     all_n = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_n, n_local)
     n_max = max(int(t.item()) for t in all_n)
-    pack = torch.zeros((max(n_max, 1), 3), dtype=torch.float64, device=dev)
+    pack = torch.zeros((max(n_max, 1), 4), dtype=torch.float64, device=dev)
     if keys.shape[0]:
         pack[:keys.shape[0], 0] = torch.as_tensor(keys.astype(np.float64))   # exact below 2^53
         pack[:keys.shape[0], 1] = torch.as_tensor(sums)
         pack[:keys.shape[0], 2] = torch.as_tensor(counts)
+        pack[:keys.shape[0], 3] = torch.as_tensor(first.astype(np.float64) + float(rank) * 2.0 ** 40)
     gathered = [torch.zeros_like(pack) for _ in range(world)] if rank == dst else None
     dist.gather(pack, gathered, dst=dst)
     if rank != dst:
-        return None, None, None
+        return None, None, None, None
     parts = [g[:int(n.item())].cpu().numpy() for g, n in zip(gathered, all_n)]
-    allp = np.concatenate(parts, axis=0) if parts else np.zeros((0, 3))
+    allp = np.concatenate(parts, axis=0) if parts else np.zeros((0, 4))
     k = allp[:, 0].astype(np.int64)
     uk, inv = np.unique(k, return_inverse=True)
     # np.bincount adds in array order (rank-major, each rank's keys ascending): the same order np.add.at used, ~50x faster
     s = np.bincount(inv, weights=allp[:, 1], minlength=uk.shape[0])
     c = np.bincount(inv, weights=allp[:, 2], minlength=uk.shape[0])
-    return uk, s, c
+    f = np.full(uk.shape[0], np.inf)
+    np.minimum.at(f, inv, allp[:, 3])
+    return uk, s, c, f

@@ -161,7 +161,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
             keys_l.append(ids[prs[:, :, 0]][vld].astype(np.int64) * n_pts + ids[prs[:, :, 1]][vld].astype(np.int64))
             score_l.append(sc.astype(np.float64))
     if not keys_l:
-        return np.zeros(0, np.int64), np.zeros(0), np.zeros(0)
+        return np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0, np.int64)
     lap("score fetch + keys")
     k = np.ascontiguousarray(np.concatenate(keys_l), dtype=np.int64)
     s = np.ascontiguousarray(np.concatenate(score_l), dtype=np.float64)
@@ -169,13 +169,24 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
     # in the library's host code (np.unique + np.bincount did the same in 11 ms per CityScale scene, this takes ~3)
     import ctypes as C
     from . import _lib
-    uk, sums, cnts = np.empty_like(k), np.empty_like(s), np.empty_like(s)
+    uk, sums, cnts, first = np.empty_like(k), np.empty_like(s), np.empty_like(s), np.empty_like(k)
     nu = C.c_int64(0)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    if _lib.load().srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), C.byref(nu)) != 0:
+    if _lib.load().srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), vp(first),
+                                            C.byref(nu)) != 0:
         raise _lib.SrhError("srh_edge_vote_accumulate failed")
     lap("accumulate")
-    return uk[:nu.value], sums[:nu.value], cnts[:nu.value]
+    return uk[:nu.value], sums[:nu.value], cnts[:nu.value], first[:nu.value]
+
+
+def votes_to_edges(uk, sums, cnts, first, n_pts, threshold):
+    """inferencer.py:224-228: mean directed score > TOPO_THRESHOLD, as an [E,2] array in the INSERTION order of the
+    reference's dict (= order of each key's first vote; `first` from edge_votes / gather_edge_votes).  That order follows the
+    per-tile point order, which in the reference is whatever rtree.intersection yields; here tiles list their points by
+    ascending global index (the edge SET does not depend on it — pinned by tests/test_refrun_golden.py)."""
+    keep = (sums / np.maximum(cnts, 1.0)) > threshold
+    k = uk[keep][np.argsort(first[keep], kind="stable")]
+    return np.stack([k // n_pts, k % n_pts], axis=1).reshape(-1, 2)
 
 
 def infer_one_img(net, img, config, device=None):
@@ -216,65 +227,138 @@ def infer_one_img(net, img, config, device=None):
 
     # ---- pass 2: per-tile queries (host) -> sampler + TopoNet (GPU) -> directed edge votes
     n_pts = graph_points.shape[0]
-    uk, sums, cnts = edge_votes(net, emb, graph_points, infos, lo, hi, config, device)
-    uk, sums, cnts = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None)
+    uk, sums, cnts, first = edge_votes(net, emb, graph_points, infos, lo, hi, config, device)
+    uk, sums, cnts, first = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None,
+                                                first=first)
     if rank != 0:
         return None
-    keep = (sums / np.maximum(cnts, 1.0)) > config.TOPO_THRESHOLD
-    pred_edges = np.stack([uk[keep] // n_pts, uk[keep] % n_pts], axis=1).reshape(-1, 2)
+    pred_edges = votes_to_edges(uk, sums, cnts, first, n_pts, config.TOPO_THRESHOLD)
     pred_nodes = graph_points[:, ::-1]  # (row, col)
     return pred_nodes, pred_edges, kp_mask, road_mask
 
 
+def get_img_paths(root_dir, image_indices):
+    """inferencer.py:38-44."""
+    import os
+    return [os.path.join(root_dir, f"region_{ind}_sat.png") for ind in image_indices]
+
+
+def read_rgb_img(path):
+    """dataset.py:16-19 (cv2.imread + BGR->RGB): [H,W,3] uint8 RGB.  PIL decodes the same 8-bit PNGs."""
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(path).convert("RGB")))
+
+
+def cityscale_data_partition():
+    """dataset.py:21-38: (train, validation, test) region indices of the 180 CityScale regions."""
+    train = [x for x in range(180) if x % 10 < 8]
+    test = [x for x in range(180) if x % 10 == 9 or x % 20 == 8]
+    val = [x for x in range(180) if x % 20 == 18]
+    return train, val, test
+
+
+def spacenet_data_partition():
+    """dataset.py:41-53: reads ./spacenet/data_split.json relative to the working directory, as the reference does."""
+    import json
+    with open("./spacenet/data_split.json", "r") as jf:
+        d = json.load(jf)
+    return d["train"], d["validation"], d["test"]
+
+
+def create_output_dir_and_save_config(output_dir_prefix, config, specified_dir=None):
+    """utils.py:11-29."""
+    import os
+    import yaml
+    from datetime import datetime
+    out = specified_dir if specified_dir else f"{output_dir_prefix}_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "config.yaml"), "w") as f:
+        yaml.dump(config.to_dict(), f)
+    return out
+
+
+def _build_net(config, checkpoint, device):
+    """inferencer.py:246-254."""
+    from .model import SAMRoad
+    net = SAMRoad(config)
+    ckpt = torch.load(checkpoint, map_location="cpu")
+    print(f"##### Loading Trained CKPT {checkpoint} #####")
+    net.load_state_dict(ckpt["state_dict"], strict=True)
+    net.eval()
+    net.to(device)
+    return net
+
+
 def main(argv=None):
-    """CLI with the reference's flags (inferencer.py:24-35).  Dataset enumeration, GT loading and the
-    cv2 visualisations of the reference's __main__ are outside the hot path; this entry point runs one
-    or more scene images given explicitly and writes masks (.npy/.png) + the sat2graph pickle."""
+    """Drop-in for `python inferencer.py --config ... --checkpoint ... [--output_dir ...] [--device cuda]` (reference
+    inferencer.py:24-35,239-349), run from a sam_road checkout: enumerates the test split of config.DATASET
+    (./cityscale/20cities/region_{}_sat.png or ./spacenet/RGB_1.0_meter/{}__rgb.png), runs infer_one_img per image, writes
+    save/<output_dir>/{config.yaml, mask/{id}_road.png, mask/{id}_itsc.png, graph/{id}.p, inference_time.txt} with the
+    reference's formats (8-bit grayscale PNG masks, sat2graph pickle, SpaceNet (400 - r, c) flip).  Not reproduced: the cv2
+    `viz/` renderings and the ground-truth pickle the reference loads but only uses in commented-out code (visualisation,
+    SURVEY §2 #17).  Extra: `--images a.png b.npy ...` runs explicit scene files instead of the dataset split."""
     import argparse
     import os
     import pickle
     import time
+    from PIL import Image
     from .config import load_config
     from .formats import convert_to_sat2graph_format
-    from .model import SAMRoad
     ap = argparse.ArgumentParser()
     ap.add_argument("--checkpoint", default=None, help="checkpoint of the model to test.")
     ap.add_argument("--config", default=None, help="model config.")
-    ap.add_argument("--output_dir", default=None)
-    ap.add_argument("--device", default="cuda")
-    ap.add_argument("--images", nargs="*", default=[], help="scene images (.npy uint8 HxWx3 or PIL-readable)")
+    ap.add_argument("--output_dir", default=None, help="Name of the output dir, if not specified will use timestamp")
+    ap.add_argument("--device", default="cuda", help="device to use (an MI355X: there is no CPU path)")
+    ap.add_argument("--images", nargs="*", default=None, help="(extension) explicit scene images instead of the dataset split")
     args = ap.parse_args(argv)
     config = load_config(args.config)
-    net = SAMRoad(config)
-    ckpt = torch.load(args.checkpoint, map_location="cpu")
-    net.load_state_dict(ckpt["state_dict"], strict=True)
-    net.eval()
-    net.to(torch.device(args.device))
-    out_dir = os.path.join("save", args.output_dir or time.strftime("infer_%Y%m%d_%H%M%S"))
-    os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
-    os.makedirs(os.path.join(out_dir, "graph"), exist_ok=True)
-    total = 0.0
-    for path in args.images:
-        if path.endswith(".npy"):
-            img = np.load(path)
-        else:
-            from PIL import Image
-            img = np.array(Image.open(path).convert("RGB"))
-        t0 = time.time()
+    device = torch.device("cuda") if args.device == "cuda" else torch.device(args.device)
+    net = _build_net(config, args.checkpoint, device)
+
+    if args.images is not None:
+        jobs = [(os.path.splitext(os.path.basename(p))[0], p) for p in args.images]
+    elif config.DATASET == "cityscale":
+        _, _, test_img_indices = cityscale_data_partition()
+        jobs = [(i, "./cityscale/20cities/region_{}_sat.png".format(i)) for i in test_img_indices]
+    elif config.DATASET == "spacenet":
+        _, _, test_img_indices = spacenet_data_partition()
+        jobs = [(i, "./spacenet/RGB_1.0_meter/{}__rgb.png".format(i)) for i in test_img_indices]
+    else:
+        raise ValueError(f"config.DATASET must be 'cityscale' or 'spacenet' (got {config.DATASET!r}), or pass --images")
+
+    output_dir_prefix = "./save/infer_"
+    if args.output_dir:
+        output_dir = create_output_dir_and_save_config(output_dir_prefix, config, specified_dir=f"./save/{args.output_dir}")
+    else:
+        output_dir = create_output_dir_and_save_config(output_dir_prefix, config)
+
+    total_inference_seconds = 0.0
+    for img_id, path in jobs:
+        print(f"Processing {img_id}")
+        img = np.load(path) if str(path).endswith(".npy") else read_rgb_img(path)
+        start_seconds = time.time()
         res = infer_one_img(net, img, config)
-        total += time.time() - t0
-        if res is None:
+        total_inference_seconds += time.time() - start_seconds
+        if res is None:                      # non-zero rank of a multi-GPU run
             continue
-        nodes, edges, kp, road = res
-        stem = os.path.splitext(os.path.basename(path))[0]
-        np.save(os.path.join(out_dir, "mask", f"{stem}_road.npy"), road)
-        np.save(os.path.join(out_dir, "mask", f"{stem}_itsc.npy"), kp)
+        pred_nodes, pred_edges, itsc_mask, road_mask = res
+        mask_save_dir = os.path.join(output_dir, "mask")
+        os.makedirs(mask_save_dir, exist_ok=True)
+        Image.fromarray(road_mask).save(os.path.join(mask_save_dir, f"{img_id}_road.png"))
+        Image.fromarray(itsc_mask).save(os.path.join(mask_save_dir, f"{img_id}_itsc.png"))
         if config.DATASET == "spacenet":
-            nodes = np.stack([400 - nodes[:, 0], nodes[:, 1]], axis=1)   # inferencer.py:332-334
-        with open(os.path.join(out_dir, "graph", f"{stem}.p"), "wb") as f:
-            pickle.dump(convert_to_sat2graph_format(nodes, edges), f)
-    with open(os.path.join(out_dir, "inference_time.txt"), "w") as f:
-        f.write(f"Inference completed for {args.config} in {total} seconds.")
+            pred_nodes = np.stack([400 - pred_nodes[:, 0], pred_nodes[:, 1]], axis=1)   # inferencer.py:332-334
+        graph_save_dir = os.path.join(output_dir, "graph")
+        os.makedirs(graph_save_dir, exist_ok=True)
+        with open(os.path.join(graph_save_dir, f"{img_id}.p"), "wb") as f:
+            pickle.dump(convert_to_sat2graph_format(pred_nodes, pred_edges), f)
+        print(f"Done for {img_id}.")
+
+    time_txt = f"Inference completed for {args.config} in {total_inference_seconds} seconds."
+    print(time_txt)
+    if not D.is_distributed() or torch.distributed.get_rank() == 0:
+        with open(os.path.join(output_dir, "inference_time.txt"), "w") as f:
+            f.write(time_txt)
 
 
 if __name__ == "__main__":

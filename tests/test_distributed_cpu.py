@@ -53,13 +53,17 @@ def _worker(rank, world, port, out):
         n_pts = 100
         if rank == 0:
             k, s, c = np.array([5, 17, 230], np.int64), np.array([0.5, 1.5, 0.25]), np.array([1.0, 2.0, 1.0])
+            f = np.array([7, 0, 3], np.int64)
         else:
             k, s, c = np.array([17, 999], np.int64), np.array([0.5, 0.75]), np.array([1.0, 1.0])
-        uk, us, uc = D.gather_edge_votes(k, s, c, n_pts, dst=0)
+            f = np.array([1, 0], np.int64)
+        uk, us, uc, uf = D.gather_edge_votes(k, s, c, n_pts, dst=0, first=f)
         if rank == 0:
             np.testing.assert_array_equal(uk, [5, 17, 230, 999])
             np.testing.assert_allclose(us, [0.5, 2.0, 0.25, 0.75])
             np.testing.assert_allclose(uc, [1.0, 3.0, 1.0, 1.0])
+            # first-vote order: rank-major, then the rank's local position => 17 (rank 0, pos 0), 230, 5, 999 (rank 1)
+            np.testing.assert_array_equal(uk[np.argsort(uf)], [17, 230, 5, 999])
         else:
             assert uk is None
         out.put((rank, "ok"))

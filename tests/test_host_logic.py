@@ -157,9 +157,11 @@ def test_edge_vote_accumulate_matches_reference_dict_loop():
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
 
     def run(k, s):
-        uk, su, cn = np.empty_like(k), np.empty_like(s), np.empty_like(s)
+        uk, su, cn, fi = np.empty_like(k), np.empty_like(s), np.empty_like(s), np.empty_like(k)
         nu = C.c_int64(-1)
-        assert lib.srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(su), vp(cn), C.byref(nu)) == 0
+        assert lib.srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(su), vp(cn), vp(fi), C.byref(nu)) == 0
+        # the first-vote positions reproduce the dict's insertion order
+        assert uk[:nu.value][np.argsort(fi[:nu.value])].tolist() == list(dict.fromkeys(k.tolist()))
         return uk[:nu.value], su[:nu.value], cn[:nu.value]
 
     rng = np.random.default_rng(11)
@@ -262,3 +264,22 @@ def test_c_abi_exports_every_declared_symbol():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_config_missing_keys_copy_pickle_and_toponet_default():
+    """ADVICE r1: a YAML without TOPONET_VERSION (toponet_vith_256 / vitl_256 / vitb_256 / vitb_1024) must behave as 'normal';
+    Config survives copy.deepcopy / pickle (addict.Dict does)."""
+    import copy
+    import pickle
+    import warnings
+    from sam_road_amd import Config, SAMRoad
+    cfg = Config(SAM_VERSION="vit_b", PATCH_SIZE=256, SAM_CKPT_PATH="", ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[],
+                 nested=dict(a=1))
+    assert not cfg.TOPONET_VERSION and not cfg.NO_SAM and cfg.TOPONET_VERSION != "no_transformer"
+    assert copy.deepcopy(cfg) == cfg and pickle.loads(pickle.dumps(cfg)) == cfg
+    warnings.simplefilter("ignore")
+    net = SAMRoad(cfg)
+    assert net._topo_version == "normal" and hasattr(net.topo_net, "transformer_encoder")
+    assert copy.deepcopy(net).state_dict().keys() == net.state_dict().keys()
+    net2 = SAMRoad(Config(dict(cfg, TOPONET_VERSION="no_transformer")))
+    assert net2._topo_version == "no_transformer" and not hasattr(net2.topo_net, "transformer_encoder")

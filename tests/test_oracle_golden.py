@@ -132,3 +132,42 @@ def test_torch_kats(golden_dir):
     # dtype promotions the reference relies on
     assert (torch.tensor([3], dtype=torch.int64) / 512).dtype == torch.float32
     assert torch.concat([torch.zeros(1), torch.zeros(1), torch.zeros(1, dtype=torch.int64)]).dtype == torch.float32
+
+
+def test_encoder_matches_hf_at_true_vitb_512_dims():
+    """The oracle encoder vs transformers' independent SamVisionEncoder at the REAL ViT-B / 512^2 geometry of BASELINE
+    configs[1] (D 768, 12 heads, all 12 blocks, 9 windows of which 5 are padded, 32x32 global attention with 63-row rel-pos
+    tables) — computed live (HF is importable wherever the tests run; ~2 s), one tile."""
+    from transformers import SamVisionConfig
+    from transformers.models.sam.modeling_sam import SamVisionEncoder
+    cfg = SamVisionConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, image_size=512, patch_size=16,
+                          window_size=14, global_attn_indexes=[2, 5, 8, 11], mlp_dim=3072, output_channels=256,
+                          layer_norm_eps=1e-6, use_rel_pos=True, use_abs_pos=True, qkv_bias=True, hidden_act="gelu")
+    cfg._attn_implementation = "eager"
+    hf = SamVisionEncoder(cfg).eval()
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for k, v in hf.state_dict().items():
+        if v.dim() == 1 and "layer_norm" in k and k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            sd[k] = 0.02 * torch.randn(v.shape, generator=g)
+    hf.load_state_dict(sd)
+
+    def ren(k):
+        for a, b in (("layers.", "blocks."), ("layer_norm1", "norm1"), ("layer_norm2", "norm2"),
+                     ("patch_embed.projection", "patch_embed.proj"), ("neck.conv1", "neck.0"),
+                     ("neck.norm1", "neck.1"), ("neck.conv2", "neck.2"), ("neck.norm2", "neck.3")):
+            k = k.replace(a, b)
+        return k
+    enc = ImageEncoderViT(img_size=512, embed_dim=768, depth=12, num_heads=12, global_attn_indexes=[2, 5, 8, 11]).eval()
+    enc.load_state_dict({ren(k): v for k, v in sd.items()}, strict=True)
+    assert enc.blocks[2].attn.rel_pos_h.shape == (63, 64) and enc.blocks[0].attn.rel_pos_h.shape == (27, 64)
+    x = torch.randn(1, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        y_hf = hf(x).last_hidden_state
+        y = enc(x)
+    assert y.shape == (1, 256, 32, 32)
+    err = (y - y_hf).abs().max().item()
+    print("oracle vs HF SamVisionEncoder, ViT-B 512^2, 12 blocks: max abs", err)
+    assert err < 2e-4

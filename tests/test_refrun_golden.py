@@ -1,0 +1,332 @@
+"""Pins the oracle (CPU tests) and the HIP path (``-m gpu`` tests) to the fixtures produced by running the REFERENCE ITSELF —
+``model.py`` and ``inferencer.py`` imported verbatim under stub modules (tests/golden/make_golden_refrun.py, ref_stubs.py).
+
+Rows of SURVEY §8 that become reference-pinned this way: a3 / a6 / a11 (the three entry points and the decoder wiring,
+model.py:414-508), a7 (mask fusion, inferencer.py:79-110), a12 (``__init__`` incl. the SAM-checkpoint resize, LoRA key layout
+and arithmetic), f1 (pass-2 builder + vote, inferencer.py:135-230), the CLI (inferencer.py:239-349).  The encoder fork (a5)
+was substituted by the oracle restatement when the fixtures were made and stays pinned to transformers' SamVisionEncoder only.
+"""
+import os
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scene as oscene
+from oracle.samroad import AttrDict, SAMRoadOracle
+from oracle.synth import synth_queries, synth_scene, synth_state_dict, synth_state_dict_keyed, synth_tiles
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _mg():
+    import importlib.util
+    import sys
+    sys.path.insert(0, GOLD)
+    spec = importlib.util.spec_from_file_location("make_golden_refrun", os.path.join(GOLD, "make_golden_refrun.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _tile_case(name):
+    P, npts, tseed, qseed = {"refrun_c1": (256, 64, 1, 9), "refrun_c2": (512, 96, 0, 7)}[name]
+    mg = _mg()
+    cfg = dict(mg.SCENE_CFG, PATCH_SIZE=P, DATASET="spacenet" if P == 256 else "cityscale", SAM_CKPT_PATH="")
+    return cfg, P, synth_tiles(1, P, seed=tseed), synth_queries(1, npts, P, seed=qseed), np.load(f"{GOLD}/{name}.npz")
+
+
+def _emb_stride(P):
+    return (P // 128) * 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU: oracle == reference
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["refrun_c1", "refrun_c2"])
+def test_oracle_entry_points_match_reference_run(name):
+    cfg, P, rgb, (points, pairs, valid), g = _tile_case(name)
+    oracle = SAMRoadOracle(AttrDict(cfg)).eval()
+    oracle.load_state_dict(synth_state_dict(oracle, 1234), strict=True)
+    ml, ms, tl, ts = oracle(rgb, points, pairs, valid)
+    ms2, emb = oracle.infer_masks_and_img_features(rgb)
+    ts2 = oracle.infer_toponet(emb, points, pairs, valid)
+    assert torch.equal(ms, ms2) and torch.equal(ts, ts2)
+    np.testing.assert_allclose(emb.numpy()[:, ::_emb_stride(P)], g["emb"], atol=1e-5)
+    s = emb.double()
+    np.testing.assert_allclose([s.sum().item(), (s * s).sum().item(), s.abs().max().item()], g["emb_sum"], rtol=1e-6)
+    np.testing.assert_allclose(ml.numpy()[:, ::4, ::4], g["mask_logits"], atol=2e-5)
+    np.testing.assert_allclose(ms.numpy()[:, ::4, ::4], g["mask_scores"], atol=1e-6)
+    assert (np.abs((ms * 255).to(torch.uint8).numpy().astype(int) - g["mask_u8"].astype(int)) <= 1).all()
+    v = valid.numpy().astype(bool)[0]
+    np.testing.assert_allclose(tl.numpy()[0, :, :, 0][v], g["topo_logits"][0, :, :, 0][v], atol=2e-5)
+    np.testing.assert_allclose(ts.numpy()[0, :, :, 0][v], g["topo_scores"][0, :, :, 0][v], atol=1e-5)
+
+
+def test_state_dict_manifest_and_sam_init_match_reference_run(tmp_path):
+    """SAMRoad.__init__ of the product vs the reference run: identical state_dict keys / shapes / order, and the
+    same outcome of the init-time SAM-checkpoint load (model.py:365-411): matched names, bilinear pos-embed and global rel-pos
+    resize, windowed tables copied, unknown keys ignored."""
+    from sam_road_amd import Config, SAMRoad
+    mg = _mg()
+    g = np.load(f"{GOLD}/refrun_init.npz")
+    ck = str(tmp_path / "fake_sam.pth")
+    mg.fake_sam_checkpoint(ck)
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(dict(mg.SCENE_CFG, SAM_CKPT_PATH=ck)))
+    sd = net.state_dict()
+    assert list(sd.keys()) == g["keys"].tolist()
+    assert [str(tuple(v.shape)) for v in sd.values()] == g["shapes"].tolist()
+    assert sorted(net.matched_param_names) == g["matched"].tolist()
+    np.testing.assert_allclose(sd["image_encoder.pos_embed"].numpy()[:, :, :, ::8], g["pos_embed"], atol=1e-7)
+    np.testing.assert_allclose(sd["image_encoder.blocks.2.attn.rel_pos_h"].numpy(), g["rel_pos_h_2"], atol=1e-7)
+    np.testing.assert_allclose(sd["image_encoder.blocks.11.attn.rel_pos_w"].numpy(), g["rel_pos_w_11"], atol=1e-7)
+    np.testing.assert_allclose(sd["image_encoder.blocks.0.attn.rel_pos_h"].numpy(), g["rel_pos_h_0"], atol=0)
+    np.testing.assert_allclose(sd["image_encoder.patch_embed.proj.bias"].numpy(), g["patch_bias"], atol=0)
+
+
+def test_lora_key_layout_matches_reference_run():
+    """ENCODER_LORA: the product's parameter tree has the reference's keys and shapes (model.py:152-186,303-347)."""
+    from sam_road_amd import Config, SAMRoad
+    mg = _mg()
+    g = np.load(f"{GOLD}/refrun_lora.npz")
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(dict(mg.SCENE_CFG, ENCODER_LORA=True, LORA_RANK=4, SAM_CKPT_PATH="")))
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == sorted(g["keys"].tolist())
+    shapes = dict(zip(g["keys"].tolist(), g["shapes"].tolist()))
+    assert all(str(tuple(v.shape)) == shapes[k] for k, v in sd.items())
+
+
+def _scene_setup():
+    mg = _mg()
+    g = np.load(f"{GOLD}/refrun_scene.npz")
+    cfg = dict(mg.SCENE_CFG, SAM_CKPT_PATH="", ITSC_THRESHOLD=float(g["itsc_threshold"]), ROAD_THRESHOLD=float(g["road_threshold"]))
+    img = synth_scene(mg.SCENE_SIZE, seed=mg.SCENE_SEED)
+    return mg, g, cfg, img
+
+
+def test_oracle_infer_one_img_matches_reference_run():
+    """oracle/scene.py (tile grid, batcher, fusion, NMS, pass-2 queries, vote) against inferencer.infer_one_img run verbatim:
+    identical u8 masks, identical nodes, identical edge set — for each of the three rtree id orders the fixture was made with
+    (the reference's result does not depend on the order rtree returns ids in; only the edge LIST order does)."""
+    mg, g, cfg, img = _scene_setup()
+    oracle = SAMRoadOracle(AttrDict(cfg)).eval()
+    oracle.load_state_dict(mg.scene_state_dict(oracle, mg.SCENE_WSEED), strict=True)
+    nodes, edges, kp, road = oscene.infer_one_img(oracle, img, AttrDict(cfg))
+    np.testing.assert_array_equal(kp, g["kp_mask"])
+    np.testing.assert_array_equal(road, g["road_mask"])
+    np.testing.assert_array_equal(nodes, g["nodes_ascending"])
+    assert nodes.shape[0] > 100 and edges.shape[0] > 500
+    want = {tuple(e) for e in g["edges_ascending"].tolist()}
+    assert {tuple(e) for e in edges.tolist()} == want
+    for mode in ("descending", "shuffled"):
+        np.testing.assert_array_equal(g[f"nodes_{mode}"], g["nodes_ascending"])
+        assert {tuple(e) for e in g[f"edges_{mode}"].tolist()} == want
+    # with ids ascending (the order the oracle's and the product's closed-box filter produce) the edge list order — the
+    # insertion order of the reference's dict, inferencer.py:209-228 — is reproduced too
+    np.testing.assert_array_equal(edges, g["edges_ascending"])
+
+
+def test_host_stages_match_reference_run():
+    """Product host stages on the reference's masks: extract_graph_points and the all-tiles query builder + vote order."""
+    from sam_road_amd import Config
+    from sam_road_amd.graph_points import extract_graph_points
+    mg, g, cfg, img = _scene_setup()
+    pts = extract_graph_points(g["kp_mask"], g["road_mask"], Config(cfg))
+    np.testing.assert_array_equal(pts[:, ::-1], g["nodes_ascending"])
+
+
+def test_cli_plumbing_matches_reference_run(tmp_path, monkeypatch):
+    """The product CLI (sam_road_amd.inferencer.main, drop-in for `python inferencer.py --config --checkpoint --output_dir
+    --device`, reference inferencer.py:239-349) on the same fake dataset directories the reference's __main__ was run on:
+    same output files (mask PNGs, graph pickles, config.yaml, inference_time.txt; the cv2 `viz/` renderings are not
+    produced), same pickle structure incl. the SpaceNet (400 - r, c) flip.  The model call is replaced by one that returns the
+    reference's own per-image results, so this runs without a GPU and checks the plumbing only (the GPU twin is
+    test_cli_end_to_end_gpu)."""
+    from sam_road_amd import inferencer as inf
+    mg = _mg()
+    g = np.load(f"{GOLD}/refrun_cli.npz")
+    for dataset in ("spacenet", "cityscale"):
+        work = tmp_path / dataset
+        ids = _make_fake_dataset(mg, work, dataset, g)
+        recorded = {}
+
+        def fake_infer(net, img, config, _ids=ids, _rec=recorded, _ds=dataset):
+            i = _ids[len(_rec)]
+            _rec[i] = img
+            key = f"{_ds}_{i}"
+            if key + "_road" not in g:
+                return np.zeros((0, 2), np.int64), np.zeros((0, 2), np.int32), np.zeros(img.shape[:2], np.uint8), np.zeros(img.shape[:2], np.uint8)
+            keys = g[key + "_graph_keys"]
+            nodes = keys.copy()
+            if _ds == "spacenet":                                  # undo the flip the CLI will apply
+                nodes = np.stack([400 - keys[:, 0], keys[:, 1]], axis=1)
+            lens, nbrs = g[key + "_graph_lens"], g[key + "_graph_nbrs"]
+            index = {tuple(k): j for j, k in enumerate(keys.tolist())}
+            edges, o = [], 0
+            for j, n in enumerate(lens.tolist()):
+                edges += [(j, index[tuple(p)]) for p in nbrs[o:o + n].tolist()]
+                o += n
+            edges = np.array([e for e in edges if e[0] < e[1]], dtype=np.int64).reshape(-1, 2)
+            return nodes, edges, g[key + "_itsc"], g[key + "_road"]
+
+        monkeypatch.setattr(inf, "infer_one_img", fake_infer)
+        monkeypatch.setattr(inf, "_build_net", lambda config, checkpoint, device: None)
+        monkeypatch.chdir(work)
+        inf.main(["--config", "cfg.yaml", "--checkpoint", "ckpt.ckpt", "--output_dir", "run1", "--device", "cpu"])
+        outdir = work / "save" / "run1"
+        files = sorted(os.path.relpath(os.path.join(d, f), outdir) for d, _, fs in os.walk(outdir) for f in fs)
+        want = [f for f in g[f"{dataset}_files"].tolist() if not f.startswith("viz")]
+        assert files == want
+        assert list(recorded.keys()) == ids                        # same images, same order as the reference's partition
+        from PIL import Image
+        for i in ids[:2]:
+            key = f"{dataset}_{i}"
+            np.testing.assert_array_equal(np.array(Image.open(outdir / "mask" / f"{i}_road.png")), g[key + "_road"])
+            np.testing.assert_array_equal(np.array(Image.open(outdir / "mask" / f"{i}_itsc.png")), g[key + "_itsc"])
+            gr = pickle.load(open(outdir / "graph" / f"{i}.p", "rb"))
+            assert sorted(gr.keys()) == sorted(tuple(k) for k in g[key + "_graph_keys"].tolist())
+            assert all(isinstance(k, tuple) and isinstance(k[0], int) for k in gr)
+        txt = open(outdir / "inference_time.txt").read()
+        assert txt.split(" in ")[0] == str(g[f"{dataset}_time_txt"]) and txt.endswith(" seconds.")
+
+
+def _make_fake_dataset(mg, work, dataset, g, with_ckpt=False):
+    import json
+    import yaml
+    from PIL import Image
+    os.makedirs(work)
+    size = 400 if dataset == "spacenet" else 288
+    cfg = dict(mg.SCENE_CFG, DATASET=dataset, SAM_CKPT_PATH="", INFER_PATCHES_PER_EDGE=2,
+               SAMPLE_MARGIN=16 if dataset == "cityscale" else 0, INFER_BATCH_SIZE=3)
+    with open(work / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    ids = g[f"{dataset}_ids"].tolist()
+    if dataset == "spacenet":
+        os.makedirs(work / "spacenet" / "RGB_1.0_meter")
+        with open(work / "spacenet" / "data_split.json", "w") as f:
+            json.dump({"train": ["x"], "validation": ["y"], "test": ids}, f)
+        pat = "spacenet/RGB_1.0_meter/{}__rgb.png"
+    else:
+        os.makedirs(work / "cityscale" / "20cities")
+        ids = [int(i) for i in ids]
+        pat = "cityscale/20cities/region_{}_sat.png"
+    for j, i in enumerate(ids):
+        Image.fromarray(synth_scene(size, seed=100 + j)).save(work / pat.format(i))
+    if with_ckpt:
+        net = SAMRoadOracle(AttrDict(cfg))
+        torch.save({"state_dict": mg.scene_state_dict(net, mg.CLI_WSEED)}, work / "ckpt.ckpt")
+    return ids
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GPU: HIP path == reference (within the stated fp16-operand tolerances)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _hip_net(cfg, sd):
+    from sam_road_amd import Config, SAMRoad
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(cfg))
+    net.load_state_dict(sd, strict=True)
+    return net.eval().to("cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["refrun_c1", "refrun_c2"])
+def test_hip_entry_points_match_reference_run(name):
+    cfg, P, rgb, (points, pairs, valid), g = _tile_case(name)
+    net = _hip_net(cfg, synth_state_dict(SAMRoadOracle(AttrDict(cfg)), 1234))
+    ml, ms, tl, ts = [t.cpu() for t in net(rgb.cuda(), points.cuda(), pairs.cuda(), valid.cuda())]
+    ms2, emb = net.infer_masks_and_img_features(rgb.cuda())
+    emb = emb.cpu()
+    e, er = emb.numpy()[:, ::_emb_stride(P)], g["emb"]
+    rel = np.linalg.norm(e - er) / np.linalg.norm(er)
+    print(name, "emb rel-l2", rel, "max", np.abs(e - er).max(), "mask", np.abs(ms.numpy()[:, ::4, ::4] - g["mask_scores"]).max())
+    assert rel < 1e-2 and np.abs(e - er).max() < 5e-2
+    assert np.abs(ms.numpy()[:, ::4, ::4] - g["mask_scores"]).max() < 2e-2
+    d = np.abs((ms * 255).to(torch.uint8).numpy().astype(int) - g["mask_u8"].astype(int))
+    assert (d <= 2).mean() >= 0.999
+    v = valid.numpy().astype(bool)[0]
+    assert np.abs(ts.numpy()[0, :, :, 0][v] - g["topo_scores"][0, :, :, 0][v]).max() < 2e-2
+    assert np.abs(tl.numpy()[0, :, :, 0][v] - g["topo_logits"][0, :, :, 0][v]).max() < 0.1
+
+
+@pytest.mark.gpu
+def test_hip_lora_fold_matches_reference_run():
+    """LoRA adapters are folded into qkv.weight at pack time (sam_road_amd/model.py); the reference applies them at run time
+    (model.py:179-185).  Non-zero B matrices; compared with the reference run's embeddings."""
+    from sam_road_amd import Config, SAMRoad
+    mg = _mg()
+    g = np.load(f"{GOLD}/refrun_lora.npz")
+    cfg = dict(mg.SCENE_CFG, ENCODER_LORA=True, LORA_RANK=4, SAM_CKPT_PATH="")
+    warnings.simplefilter("ignore")
+    net = SAMRoad(Config(cfg))
+    net.load_state_dict(synth_state_dict_keyed(net, 4242), strict=True)
+    net.eval().to("cuda")
+    ms, emb = net.infer_masks_and_img_features(synth_tiles(1, 256, seed=3).cuda())
+    e, er = emb.cpu().numpy()[:, ::2], g["emb"]
+    rel = np.linalg.norm(e - er) / np.linalg.norm(er)
+    print("lora emb rel-l2", rel)
+    assert rel < 1e-2 and np.abs(ms.cpu().numpy()[:, ::4, ::4] - g["mask_scores"]).max() < 2e-2
+    # and the adapters matter: without them the embeddings move by far more than the tolerance
+    sd = {k: (torch.zeros_like(v) if ".linear_b_" in k else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
+    _, emb0 = net.infer_masks_and_img_features(synth_tiles(1, 256, seed=3).cuda())
+    assert np.linalg.norm(emb0.cpu().numpy()[:, ::2] - er) / np.linalg.norm(er) > 5 * rel
+
+
+@pytest.mark.gpu
+def test_hip_infer_one_img_matches_reference_run():
+    """infer_one_img on the HIP path vs inferencer.infer_one_img run verbatim: masks within +-2 u8 levels (+-1 on 99.9 %),
+    and — greedy NMS being chaotic w.r.t. single u8 levels — the graph stage-wise: on the REFERENCE's nodes the product's
+    pass 2 must reproduce the reference's edge list (set equality up to decisions within 0.003 of the threshold, list order
+    equal when the sets are)."""
+    from sam_road_amd import Config
+    from sam_road_amd.inferencer import edge_votes, infer_one_img, votes_to_edges
+    from sam_road_amd.tiling import get_patch_info_one_img
+    mg, g, cfg, img = _scene_setup()
+    net = _hip_net(cfg, mg.scene_state_dict(SAMRoadOracle(AttrDict(cfg)), mg.SCENE_WSEED))
+    nodes, edges, kp, road = infer_one_img(net, img, Config(cfg))
+    for got, ref in ((kp, g["kp_mask"]), (road, g["road_mask"])):
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 2 and (d <= 1).mean() >= 0.999
+    # pass 2 on the reference's own point set
+    pts = np.ascontiguousarray(g["nodes_ascending"][:, ::-1])
+    infos = get_patch_info_one_img(0, img.shape[0], cfg["SAMPLE_MARGIN"], cfg["PATCH_SIZE"], cfg["INFER_PATCHES_PER_EDGE"])
+    xy = torch.tensor([[p[1][0], p[1][1]] for p in infos], dtype=torch.int32).cuda()
+    _, _, emb = net.scene_pass1(torch.as_tensor(img).cuda(), xy, cfg["INFER_BATCH_SIZE"])
+    uk, sums, cnts, first = edge_votes(net, emb, pts, infos, 0, len(infos), Config(cfg), torch.device("cuda"))
+    got_edges = votes_to_edges(uk, sums, cnts, first, pts.shape[0], cfg["TOPO_THRESHOLD"])
+    want = [tuple(e) for e in g["edges_ascending"].tolist()]
+    got = [tuple(e) for e in got_edges.tolist()]
+    mean = dict(zip(uk.tolist(), (sums / cnts).tolist()))
+    n = pts.shape[0]
+    shaky = {e for e in set(got) ^ set(want) if abs(mean.get(e[0] * n + e[1], 0.0) - cfg["TOPO_THRESHOLD"]) <= 0.003}
+    print("edges", len(got), "reference", len(want), "differing (all within 0.003 of the threshold):", len(shaky))
+    assert (set(got) ^ set(want)) == shaky and len(shaky) <= max(2, 0.01 * len(want))
+    assert [e for e in got if e not in shaky] == [e for e in want if e not in shaky]       # the reference's list ORDER
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_gpu(tmp_path, monkeypatch):
+    """`python -m sam_road_amd.inferencer --config --checkpoint --output_dir` on the fake spacenet directory, for real."""
+    from PIL import Image
+    from sam_road_amd import inferencer as inf
+    mg = _mg()
+    g = np.load(f"{GOLD}/refrun_cli.npz")
+    work = tmp_path / "spacenet"
+    ids = _make_fake_dataset(mg, work, "spacenet", g, with_ckpt=True)
+    monkeypatch.chdir(work)
+    inf.main(["--config", "cfg.yaml", "--checkpoint", "ckpt.ckpt", "--output_dir", "run1"])
+    outdir = work / "save" / "run1"
+    for i in ids:
+        for kind in ("road", "itsc"):
+            got = np.array(Image.open(outdir / "mask" / f"{i}_{kind}.png"))
+            d = np.abs(got.astype(int) - g[f"spacenet_{i}_{kind}"].astype(int))
+            assert d.max() <= 2 and (d <= 1).mean() >= 0.999
+        gr = pickle.load(open(outdir / "graph" / f"{i}.p", "rb"))
+        assert isinstance(gr, dict)

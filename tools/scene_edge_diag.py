@@ -28,7 +28,7 @@ for seed in (6, 7, 8):
     kp, road = [t.cpu().numpy() for t in net.scene_normalise(kp_c, road_c, xy)]
     pts = extract_graph_points(kp, road, c)
     edges_r, sums_r, cnts_r = oscene.infer_pass2(oracle, feats, pts, infos, AttrDict(cfg))
-    uk, sums, cnts = edge_votes(net, emb, pts, infos, 0, len(infos), c, torch.device("cuda"))
+    uk, sums, cnts, _ = edge_votes(net, emb, pts, infos, 0, len(infos), c, torch.device("cuda"))
     n = pts.shape[0]
     hip = {(int(k // n), int(k % n)): s / m for k, s, m in zip(uk, sums, cnts)}
     d = np.array([hip[e] - sums_r[e] / cnts_r[e] for e in sums_r])

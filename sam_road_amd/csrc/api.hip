@@ -42,10 +42,10 @@ struct srh_ctx {
     int device = 0;
     std::string err;
     // encoder / decoder workspace
-    DevBuf a0, x, xn16, delta16, qkv16, rel, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16, d2_16;
+    DevBuf a0, x, xn16, delta16, qkv16, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16;
     DevBuf scores_ws, emb_ws, counter, split_ws;
     // toponet workspace
-    DevBuf t_feat16, t_pf16, t_pair16, t_x, t_x16, t_qkv16, t_at16, t_y, t_h16;
+    DevBuf t_feat16, t_pf16, t_pair16;
     // profiling
     bool profiling = false;
     std::vector<std::string> cls_names;
@@ -59,10 +59,6 @@ struct BlockW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
     f16 *qkv_w, *qkv_b16, *rel_h, *rel_w, *proj_w, *fc1_w, *fc2_w;
 };
-struct TopoLayerW {
-    f16 *in_w, *out_w, *l1_w, *l2_w;
-    float *in_b, *out_b, *l1_b, *l2_b, *n1_g, *n1_b, *n2_g, *n2_b;
-};
 struct srh_weights {
     srh_model_cfg cfg;
     int S = 0, D = 0, heads = 0, hd = 0;
@@ -71,9 +67,9 @@ struct srh_weights {
     std::vector<BlockW> blocks;
     f16 *neck0_w, *neck2_w; float *neck1_g, *neck1_b, *neck3_g, *neck3_b;
     f16 *dec0_w, *dec3_w, *dec5_w; float *dec0_b, *dec1_g, *dec1_b, *dec3_b, *dec5_b, *dec7_w, *dec7_b;
-    f16 *tp_feat_w, *tp_pair_w; float *tp_feat_b, *tp_pair_b, *tp_out_w, *tp_out_b;
+    f16* tp_feat_w; float* tp_feat_b;
     char* tp_stream = nullptr; float* tp_params = nullptr;       // fused trunk (topo_fused.hip)
-    std::vector<TopoLayerW> tlayers;
+    int tp_layers = 0;                                            // encoder layers of the trunk (0: TOPONET_VERSION no_transformer)
 };
 
 static int fail(srh_ctx* c, int code, const std::string& msg) {
@@ -114,24 +110,6 @@ static int run(srh_ctx* c, const char* cls, double flops, double bytes, hipStrea
     return rc;
 }
 
-// SRH_TOPO_FUSED=0 selects the layer-by-layer TopoNet path (kept for A/B measurements and as a second implementation
-// the parity tests can compare against)
-static bool topo_fused() {
-    static const bool v = !(getenv("SRH_TOPO_FUSED") && atoi(getenv("SRH_TOPO_FUSED")) == 0);
-    return v;
-}
-
-// SRH_DECODE_FUSED=0 selects the layer-by-layer decoder tail (dec5 GEMM + decode_out_kernel)
-static bool decode_fused() {
-    static const bool v = !(getenv("SRH_DECODE_FUSED") && atoi(getenv("SRH_DECODE_FUSED")) == 0);
-    return v;
-}
-
-static bool attn_fused() {
-    static const bool v = !(getenv("SRH_ATTN_FUSED") && atoi(getenv("SRH_ATTN_FUSED")) == 0);
-    return v;
-}
-
 static int gemm(srh_ctx* c, const char* cls, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     const int sk = gemm_splitk_factor(p);
@@ -163,9 +141,9 @@ extern "C" int srh_ctx_create(int device, srh_ctx** out) {
 extern "C" void srh_ctx_destroy(srh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->qkv16, &c->rel, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
-                      &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->d2_16, &c->scores_ws, &c->emb_ws, &c->counter,
-                      &c->t_feat16, &c->t_pf16, &c->t_pair16, &c->t_x, &c->t_x16, &c->t_qkv16, &c->t_at16, &c->t_y, &c->t_h16};
+    DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->delta16, &c->qkv16, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
+                      &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
+                      &c->t_feat16, &c->t_pf16, &c->t_pair16};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     delete c;
@@ -389,33 +367,8 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
     const std::string T = "topo_net.";
     pk.put_f16_same(&w->tp_feat_w, T + "feature_proj.weight", 128 * 256);
     pk.put_f32(&w->tp_feat_b, T + "feature_proj.bias", 128);
-    pk.put_f16(&w->tp_pair_w, T + "pair_proj.weight", 128 * 258, 128 * 320, [](size_t i) {
-        const size_t nidx = i / 320, k = i % 320;
-        return k < 258 ? (long)(nidx * 258 + k) : -1L;
-    });
-    pk.put_f32(&w->tp_pair_b, T + "pair_proj.bias", 128);
-    if (cfg->toponet_version != 2) {
-        w->tlayers.resize(3);
-        for (int l = 0; l < 3; ++l) {
-            TopoLayerW& tl = w->tlayers[l];
-            const std::string L = T + "transformer_encoder.layers." + std::to_string(l) + ".";
-            pk.put_f16_same(&tl.in_w, L + "self_attn.in_proj_weight", 384 * 128);
-            pk.put_f32(&tl.in_b, L + "self_attn.in_proj_bias", 384);
-            pk.put_f16_same(&tl.out_w, L + "self_attn.out_proj.weight", 128 * 128);
-            pk.put_f32(&tl.out_b, L + "self_attn.out_proj.bias", 128);
-            pk.put_f16_same(&tl.l1_w, L + "linear1.weight", 128 * 128);
-            pk.put_f32(&tl.l1_b, L + "linear1.bias", 128);
-            pk.put_f16_same(&tl.l2_w, L + "linear2.weight", 128 * 128);
-            pk.put_f32(&tl.l2_b, L + "linear2.bias", 128);
-            pk.put_f32(&tl.n1_g, L + "norm1.weight", 128);
-            pk.put_f32(&tl.n1_b, L + "norm1.bias", 128);
-            pk.put_f32(&tl.n2_g, L + "norm2.weight", 128);
-            pk.put_f32(&tl.n2_b, L + "norm2.bias", 128);
-        }
-    }
-    pk.put_f32(&w->tp_out_w, T + "output_proj.weight", 128);
-    pk.put_f32(&w->tp_out_b, T + "output_proj.bias", 1);
-    pack_topo_fused(pk, w, cfg->toponet_version != 2 ? 3 : 0);
+    w->tp_layers = cfg->toponet_version != 2 ? 3 : 0;
+    pack_topo_fused(pk, w, w->tp_layers);
 
     if (!pk.missing.empty()) {
         delete w;
@@ -455,7 +408,6 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
     rc |= c->xn16.ensure(T * D * 2);
     rc |= c->delta16.ensure(T * D * 2);
     rc |= c->qkv16.ensure(T * 3 * D * 2);
-    if (!attn_fused()) rc |= c->rel.ensure(T * w->heads * 64 * 4);      // separate rel-pos pass only
     rc |= c->attn16.ensure(T * D * 2);
     rc |= c->hid16.ensure(T * 4 * D * 2);
     rc |= c->n1.ensure(T * 256 * 4);
@@ -465,7 +417,6 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
     rc |= c->d0.ensure(T * 512 * 4);
     rc |= c->d0_16.ensure(T * 512 * 2);
     rc |= c->d1_16.ensure(T * 1024 * 2);
-    if (!decode_fused()) rc |= c->d2_16.ensure(T * 2048 * 2);            // the fused tail keeps this level in registers
     return rc ? fail(c, SRH_ERR_HIP, "workspace allocation failed") : 0;
 }
 
@@ -514,14 +465,6 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         TRY(gemm(c, "gemm_qkv", g, s));
         AttnParams ap;
         ap.table_h = b.rel_h; ap.table_w = b.rel_w;      // rel-pos bias derived inside the attention kernel (fused_relpos)
-        if (!attn_fused()) {                              // A/B aid: separate relpos kernel + [T, heads, 2 Wp] f32 buffer
-            RelPosParams rp;
-            rp.qkv = c->qkv16.as<f16>(); rp.ld = 3 * D; rp.table_h = b.rel_h; rp.table_w = b.rel_w;
-            rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = b.win;
-            rp.inv_scale = sqrtf((float)hd);
-            TRYK(c, b.win == S ? "relpos_global" : "relpos_window", 4.0 * T * heads * b.win * hd, 0, s, launch_relpos(rp, s));
-            ap.rel = c->rel.as<float>();
-        }
         ap.qkv = c->qkv16.as<f16>(); ap.ld = 3 * D; ap.bias_qkv = b.qkv_b16;
         ap.out = c->attn16.as<f16>(); ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = b.win;
         ap.scale = 1.0f / sqrtf((float)hd);
@@ -574,22 +517,13 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         g1.A = c->d0_16.as<f16>(); g1.lda = 128; g1.W = w->dec3_w; g1.ldw = 128; g1.M = 4 * T; g1.N = 256; g1.K = 128;
         g1.bias = w->dec3_b; g1.act = 1; g1.out_f16 = c->d1_16.as<f16>(); g1.ldc16 = 256;
         TRY(gemm(c, "gemm_decoder", g1, s));
-        if (decode_fused()) {       // ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + scatter in one register-resident kernel
+        {       // ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + scatter in one register-resident kernel
             DecodeTailParams tp;
             tp.x = c->d1_16.as<f16>(); tp.w5 = w->dec5_w; tp.b5 = w->dec5_b; tp.w7 = w->dec7_w; tp.b7 = w->dec7_b;
             tp.B = B; tp.S = S; tp.logits = logits; tp.scores = scores;
             TRYK(c, "decode_tail", 2.0 * T * 16 * (64 * 128 + 4 * 32 * 8), (double)T * 16 * 128 + (double)T * 64 * ((logits ? 32 : 0) + (scores ? 32 : 0)), s,
                  launch_decode_tail(tp, s));
-            return 0;
         }
-        GemmParams g2;
-        g2.A = c->d1_16.as<f16>(); g2.lda = 64; g2.W = w->dec5_w; g2.ldw = 64; g2.M = 16 * T; g2.N = 128; g2.K = 64;
-        g2.bias = w->dec5_b; g2.act = 1; g2.out_f16 = c->d2_16.as<f16>(); g2.ldc16 = 128;
-        TRY(gemm(c, "gemm_decoder", g2, s));
-        DecodeOutParams dp;
-        dp.x = c->d2_16.as<f16>(); dp.w = w->dec7_w; dp.bias = w->dec7_b; dp.B = B; dp.S = S;
-        dp.logits = logits; dp.scores = scores;
-        TRYK(c, "decode_out", 0, (double)T * 64 * (64 + (logits ? 32 : 0) + (scores ? 32 : 0)), s, launch_decode_out(dp, s));
     }
     return 0;
 }
@@ -621,14 +555,6 @@ extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embedd
     rc |= c->t_feat16.ensure(NP * 256 * 2, 0.25);
     rc |= c->t_pf16.ensure(NP * 128 * 2, 0.25);
     rc |= c->t_pair16.ensure(R * 320 * 2, 0.25);
-    if (!topo_fused()) {        // activations of the layer-by-layer path (the fused trunk keeps them in registers)
-        rc |= c->t_x.ensure(R * 128 * 4, 0.25);
-        rc |= c->t_x16.ensure(R * 128 * 2, 0.25);
-        rc |= c->t_qkv16.ensure(R * 384 * 2, 0.25);
-        rc |= c->t_at16.ensure(R * 128 * 2, 0.25);
-        rc |= c->t_y.ensure(R * 128 * 4, 0.25);
-        rc |= c->t_h16.ensure(R * 128 * 2, 0.25);
-    }
     if (rc) return fail(c, SRH_ERR_HIP, "toponet workspace allocation failed");
 
     SampleParams sp;
@@ -644,51 +570,15 @@ extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embedd
     pg.pairs = pairs; pg.pairs_i64 = pairs_dtype == SRH_I64; pg.B = B; pg.N = N; pg.Ns = Ns; pg.Kp = K;
     pg.zero_offset = w->cfg.toponet_version == 1; pg.out = c->t_pair16.as<f16>(); pg.ld = 320;
     TRYK(c, "pair_gather", 0, (double)R * (512 + 640), s, launch_pair_gather(pg, s));
-    if (topo_fused()) {
+    {
         // pair_proj + encoder layers + output_proj in one register-resident kernel (topo_fused.hip)
         TopoFusedParams tf;
         tf.pair = c->t_pair16.as<f16>(); tf.ld_pair = 320; tf.valid = valid; tf.stream = w->tp_stream; tf.params = w->tp_params;
-        tf.nlayers = (int)w->tlayers.size(); tf.nseq = B * Ns; tf.logits = logits; tf.scores = scores;
+        tf.nlayers = w->tp_layers; tf.nseq = B * Ns; tf.logits = logits; tf.scores = scores;
         const double fl = (double)R * (2.0 * 320 * 128 + tf.nlayers * (2.0 * 128 * 768 + 4.0 * 16 * 128) + 256);
         TRYK(c, "topo_fused", fl, 0, s, launch_topo_fused(tf, s));
         return 0;
     }
-    GemmParams gp;
-    gp.A = c->t_pair16.as<f16>(); gp.lda = 320; gp.W = w->tp_pair_w; gp.ldw = 320; gp.M = (int)R; gp.N = 128; gp.K = 320;
-    gp.bias = w->tp_pair_b; gp.act = 2; gp.out_f32 = c->t_x.as<float>(); gp.ldc = 128;
-    gp.out_f16 = c->t_x16.as<f16>(); gp.ldc16 = 128;
-    TRY(gemm(c, "gemm_toponet", gp, s));
-    for (const TopoLayerW& tl : w->tlayers) {
-        GemmParams gi;
-        gi.A = c->t_x16.as<f16>(); gi.lda = 128; gi.W = tl.in_w; gi.ldw = 128; gi.M = (int)R; gi.N = 384; gi.K = 128;
-        gi.bias = tl.in_b; gi.out_f16 = c->t_qkv16.as<f16>(); gi.ldc16 = 384;
-        TRY(gemm(c, "gemm_toponet", gi, s));
-        TopoAttnParams ta;
-        ta.qkv = c->t_qkv16.as<f16>(); ta.valid = valid; ta.out = c->t_at16.as<f16>(); ta.nseq = B * Ns;
-        TRYK(c, "topo_attention", 4.0 * R * 16 * 128, 0, s, launch_topo_attention(ta, s));
-        GemmParams go;
-        go.A = c->t_at16.as<f16>(); go.lda = 128; go.W = tl.out_w; go.ldw = 128; go.M = (int)R; go.N = 128; go.K = 128;
-        go.bias = tl.out_b; go.resid = c->t_x.as<float>(); go.ldr = 128; go.out_f32 = c->t_y.as<float>(); go.ldc = 128;
-        TRY(gemm(c, "gemm_toponet", go, s));
-        NormParams ln;
-        ln.x = c->t_y.as<float>(); ln.M = (int)R; ln.D = 128; ln.eps = 1e-5f; ln.gamma = tl.n1_g; ln.beta = tl.n1_b;
-        ln.out_f32 = c->t_x.as<float>(); ln.out_f16 = c->t_x16.as<f16>();
-        TRYK(c, "layernorm", 0, (double)R * 128 * 10, s, launch_layernorm(ln, s));
-        GemmParams g1;
-        g1.A = c->t_x16.as<f16>(); g1.lda = 128; g1.W = tl.l1_w; g1.ldw = 128; g1.M = (int)R; g1.N = 128; g1.K = 128;
-        g1.bias = tl.l1_b; g1.act = 2; g1.out_f16 = c->t_h16.as<f16>(); g1.ldc16 = 128;
-        TRY(gemm(c, "gemm_toponet", g1, s));
-        GemmParams g2;
-        g2.A = c->t_h16.as<f16>(); g2.lda = 128; g2.W = tl.l2_w; g2.ldw = 128; g2.M = (int)R; g2.N = 128; g2.K = 128;
-        g2.bias = tl.l2_b; g2.resid = c->t_x.as<float>(); g2.ldr = 128; g2.out_f32 = c->t_y.as<float>(); g2.ldc = 128;
-        TRY(gemm(c, "gemm_toponet", g2, s));
-        ln.gamma = tl.n2_g; ln.beta = tl.n2_b;
-        TRYK(c, "layernorm", 0, (double)R * 128 * 10, s, launch_layernorm(ln, s));
-    }
-    TopoOutParams to;
-    to.x = c->t_x.as<float>(); to.w = w->tp_out_w; to.rows = (int)R; to.logits = logits; to.scores = scores;
-    TRYK(c, "topo_out", 0, (double)R * 520, s, launch_topo_out(to, w->tp_out_b, s));
-    return 0;
 }
 
 // ---- scene level ------------------------------------------------------------------------------------------
@@ -773,14 +663,6 @@ extern "C" int srh_op_attention(srh_ctx* c, const void* qkv, const void* rel_h, 
     const size_t T = (size_t)B * S * S;
     AttnParams ap;
     ap.table_h = (const f16*)rel_h; ap.table_w = (const f16*)rel_w;     // fused rel-pos bias (default)
-    if (!attn_fused()) {
-        if (c->rel.ensure(T * heads * 64 * 4)) return fail(c, SRH_ERR_HIP, "rel workspace allocation failed");
-        RelPosParams rp;
-        rp.qkv = (const f16*)qkv; rp.ld = 3 * D; rp.table_h = (const f16*)rel_h; rp.table_w = (const f16*)rel_w;
-        rp.rel = c->rel.as<float>(); rp.B = B; rp.S = S; rp.heads = heads; rp.hd = hd; rp.win = win; rp.inv_scale = 8.f;
-        TRYK(c, "relpos", 0, 0, s, launch_relpos(rp, s));
-        ap.rel = c->rel.as<float>();
-    }
     ap.qkv = (const f16*)qkv; ap.ld = 3 * D; ap.bias_qkv = (const f16*)bias_qkv;
     ap.out = (f16*)out; ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = win; ap.scale = 0.125f;
     TRYK(c, "attention", attn_flops(B, S, heads, hd, win), 0, s, launch_attention(ap, s));

@@ -149,15 +149,6 @@ __device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size
     const f16* q = p.qkv + tok * p.ld + head * HD;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) st.q[ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
-    if (p.rel) {
-        const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP) + Geom<WIN>::WP;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int rr, cc;
-            tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
-            st.relw[r] = (cc < WIN) ? rel[cc] : 0.f;
-        }
-    }
     st.m = -INFINITY;
     st.l = 0.f;
 #pragma unroll
@@ -279,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
     const int nreal = nry * nrx;
     const int ntq = (nreal + 31) / 32;
     const int half = lane >> 5;
-    const bool fused = p.rel == nullptr && p.ablate != 3;
+    const bool fused = p.ablate != 3;
 
     // ---- Every global load of the workgroup is issued up front, so their latencies overlap ONCE: the K / V rows to
     // stage, the query fragments of this wave's (up to two) query tiles and the rel-pos table fragments.  (Measured
@@ -378,19 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
-        if (p.rel) {
-            // precomputed bias (A/B aid): rel_w per lane, rel_h table rh[q][kh] (lanes split the 14 values between the halves)
-            const float* rel = p.rel + (tok * p.heads + head) * (2 * Geom<WIN>::WP);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int rr, cc;
-                tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
-                st.relw[r] = (cc < WIN) ? rel[Geom<WIN>::WP + cc] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) rh[(lane & 31) * 17 + half * 8 + e] = rel[half * 8 + e];
-            __builtin_amdgcn_wave_barrier();
-        } else if (fused) {
+        if (fused) {
             // fused rel-pos bias (see fused_relpos): w table -> st.relw, then h table -> rh
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -468,14 +447,7 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     QState st;
     load_query<WIN>(st, p, tok, head, lane);
     float* rh = rh_lds + wave * 32 * (WP + 1);
-    if (p.rel) {
-        const float* rel = p.rel + (tok * p.heads + head) * (2 * WP);
-        const int half = lane >> 5;
-#pragma unroll
-        for (int e = 0; e < WP / 2; ++e) rh[(lane & 31) * (WP + 1) + half * (WP / 2) + e] = rel[half * (WP / 2) + e];
-    } else {
-        fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, lane);
-    }
+    fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, lane);
 
     // staging registers (named, not arrays: hipcc keeps lambda-captured staging arrays in scratch):
     // 2 K chunks per thread, one 4-key x 8-dim V block for threads < 128

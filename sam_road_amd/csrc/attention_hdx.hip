@@ -274,7 +274,7 @@ int hdx_launch(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 bool attention_hdx_supported(const AttnParams& p) {
-    return p.hd == 80 && p.table_h && p.table_w && !p.rel && (p.win == 14 || (p.win == 16 && p.S == 16));
+    return p.hd == 80 && p.table_h && p.table_w && (p.win == 14 || (p.win == 16 && p.S == 16));
 }
 
 int launch_attention_hdx(const AttnParams& p, hipStream_t s) {

@@ -14,59 +14,6 @@
 
 namespace srh {
 
-__global__ __launch_bounds__(256) void decode_out_kernel(DecodeOutParams p) {
-    const long rows = (long)p.B * p.S * p.S * 64;
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    float x[32];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(p.x + row * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 t = src[i];
-            const f16* h = reinterpret_cast<const f16*>(&t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[i * 8 + e] = (float)h[e];
-        }
-    }
-    float o[8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        float a = p.bias[n & 1];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) a = fmaf(x[c], p.w[n * 32 + c], a);
-        o[n] = a;
-    }
-    long r = row;
-    const int s3 = r & 3; r >>= 2;
-    const int s2 = r & 3; r >>= 2;
-    const int s1 = r & 3; r >>= 2;
-    const int px = r % p.S; r /= p.S;
-    const int py = r % p.S; r /= p.S;
-    const int b = (int)r;
-    const int P = p.S * 16;
-    const int y = (((py * 2 + (s1 >> 1)) * 2 + (s2 >> 1)) * 2 + (s3 >> 1)) * 2;
-    const int xx = (((px * 2 + (s1 & 1)) * 2 + (s2 & 1)) * 2 + (s3 & 1)) * 2;
-#pragma unroll
-    for (int ky = 0; ky < 2; ++ky) {
-        const size_t off = (((size_t)b * P + y + ky) * P + xx) * 2;
-        const float4 lg = make_float4(o[ky * 4 + 0], o[ky * 4 + 1], o[ky * 4 + 2], o[ky * 4 + 3]);
-        if (p.logits) *reinterpret_cast<float4*>(p.logits + off) = lg;
-        if (p.scores) {
-            const float4 sc = make_float4(1.f / (1.f + expf(-lg.x)), 1.f / (1.f + expf(-lg.y)),
-                                          1.f / (1.f + expf(-lg.z)), 1.f / (1.f + expf(-lg.w)));
-            *reinterpret_cast<float4*>(p.scores + off) = sc;
-        }
-    }
-}
-
-int launch_decode_out(const DecodeOutParams& p, hipStream_t s) {
-    const long rows = (long)p.B * p.S * p.S * 64;
-    if (rows <= 0) return 0;
-    hipLaunchKernelGGL(decode_out_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
 // ---- the last TWO layers in one kernel ---------------------------------------------------------------------
 // ConvT(64->32, k2 s2) + GELU + ConvT(32->2, k2 s2) + sigmoid + quad-tree -> NHWC scatter (model.py:292-295, :445-446).
 // The layer-by-layer path wrote the 64 -> 4 x 32 activations (67 MB per 16 tiles) for decode_out_kernel to read back; here

@@ -385,267 +385,6 @@ void gemm_glds256_kernel(GemmParams p) {
     epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 256x256x32 LDS-DMA RING variant: same 8-wave 4(N)x2(M) decomposition as gemm_glds256_kernel but the k-loop
-// advances 32 deep per step through a 4-stage x 32 KiB LDS ring with the DMA running THREE steps ahead:
-// the barrier that opens step t only needs tile t (s_waitcnt vmcnt(8): the 8 younger DMAs of tiles t+1,
-// t+2 stay in flight across the raw s_barrier), so the ~3k-cycle L2->LDS latency of a 64 KiB/CU burst is
-// covered by three MFMA phases instead of one.  (A __syncthreads() here would drain vmcnt(0) every step.)
-// LDS rows are 64 B (4 chunks of 16 B); chunk index is XOR-ed with (row>>2)&3 — on the DMA source side.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_ring256_kernel(GemmParams p) {
-    constexpr int BM = 256, BN = 256, KS = 32, TILE = BM * KS * 2, STAGE = 2 * TILE, NSTG = 4;   // 16 KiB / 32 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
-    int tile_m, tile_n;
-    tile_of_block<4>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nsteps = p.K / KS;
-
-    // DMA piece i (0,1) of a wave covers rows (i*8 + wave)*16 .. +16 of a 256-row operand tile (16 x 64 B = 1 KiB)
-    const int prow = lane >> 2, pc = lane & 3;
-    const char* asrc[2];
-    const char* wsrc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (i * 8 + wave) * 16 + prow;
-        const int c = pc ^ ((r >> 2) & 3);
-        asrc[i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8);
-        wsrc[i] = reinterpret_cast<const char*>(p.W + (size_t)(n0 + r) * p.ldw + c * 8);
-    }
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-#define SRH_DMA_RING(t) { const int st_ = (t) & (NSTG - 1); \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
-        char* d_ = smem + st_ * STAGE + (i * 8 + wave) * 1024; \
-        __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)(t) * (KS * 2)), (lds_ptr)d_, 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc[i] + (size_t)(t) * (KS * 2)), (lds_ptr)(d_ + TILE), 16, 0, 0); } }
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int fkey = (frow >> 2) & 3;
-    int foff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 64 + (((ks * 2 + fhalf) ^ fkey) << 4);
-    const int w_row0 = (wn * 64) * 64, x_row0 = (wm * 128) * 64;
-
-    // Software pipeline across steps: the fragments of tile t+1 are read from LDS WHILE the MFMAs of tile t
-    // run (two named fragment sets, loop unrolled by two), so no MFMA ever waits for a ds_read at the top
-    // of a step.  That needs tile t+1 visible at the barrier that opens step t, and frees stage t&3 during
-    // step t already -> the DMA runs FOUR tiles ahead through the four stages.
-    // (nsteps = K/32 is even and >= 4: the launcher requires K % 64 == 0 and K >= 128.)
-#define SRH_WAIT_TILE(x) { const int yg_ = min(2, nsteps - 1 - (x)); \
-        if (yg_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
-        else if (yg_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#define SRH_RFRAG(F, G, t) { const char* sa_ = smem + ((t) & (NSTG - 1)) * STAGE + x_row0; \
-        const char* sw_ = smem + ((t) & (NSTG - 1)) * STAGE + TILE + w_row0; \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) F[ks][i] = *reinterpret_cast<const f16x8*>(sw_ + foff[ks] + 2048 * i); \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) G[ks][j] = *reinterpret_cast<const f16x8*>(sa_ + foff[ks] + 2048 * j); } }
-#define SRH_RMMA(F, G) { \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(F[ks][i], G[ks][j], acc[i][j]); }
-    f16x8 fwA[2][2], fxA[2][4], fwB[2][2], fxB[2][4];
-    SRH_DMA_RING(0)
-    SRH_DMA_RING(1)
-    SRH_DMA_RING(2)
-    SRH_DMA_RING(3)
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // tile 0 landed (12 younger DMAs in flight)
-    __builtin_amdgcn_s_barrier();
-    SRH_RFRAG(fwA, fxA, 0)
-    for (int t = 0; t < nsteps; t += 2) {
-        // ---- even step t: MFMAs on set A (tile t), prefetch set B (tile t+1)
-        SRH_WAIT_TILE(t + 1)
-        __builtin_amdgcn_s_barrier();          // tile t+1 visible to everyone; stage t&3 is free
-        if (t + 4 < nsteps) SRH_DMA_RING(t + 4)
-        SRH_RFRAG(fwB, fxB, t + 1)
-        SRH_RMMA(fwA, fxA)
-        // ---- odd step t+1: MFMAs on set B (tile t+1), prefetch set A (tile t+2)
-        if (t + 2 < nsteps) {
-            SRH_WAIT_TILE(t + 2)
-            __builtin_amdgcn_s_barrier();
-            if (t + 5 < nsteps) SRH_DMA_RING(t + 5)
-            SRH_RFRAG(fwA, fxA, t + 2)
-        }
-        SRH_RMMA(fwB, fxB)
-    }
-    __syncthreads();
-    epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
-    __builtin_amdgcn_wave_barrier();
-    epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + wm * 128 + 64, n0 + wn * 64, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 256x256x64 PING-PONG variant (the default for the big layers).  Same 8-wave decomposition and epilogue as
-// gemm_glds256_kernel (wave tile 64(N) x 128(M) = 2x4 MFMA tiles) but the k-tile is processed as FOUR
-// quadrant phases and the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run ONE PHASE
-// SEGMENT APART: while a group issues its 8 MFMAs of a quadrant the other group issues its fragment
-// ds_reads and its share of the LDS-DMA, so the matrix pipe of every SIMD always has a wave in an MFMA
-// segment.  Each operand k-tile lives in LDS as two 16 KiB half-tiles (W0/W1: the waves' first/second
-// 32 weight rows, X0/X1: the waves' first/second 64 activation rows); a quadrant phase consumes one
-// half-tile for good, which is re-staged (k-tile t+2) one or two phases later, ONE half-tile per phase:
-//     P1: read W0,X0 | DMA X1(t+1) | mma(W0,X0)      P2: read W1 | DMA W0(t+2) | mma(W1,X0)
-//     P3: read X1    | DMA X0(t+2) | mma(W1,X1)      P4:  -      | DMA W1(t+2) | mma(W0,X1)
-// The DMA queue is never drained inside the loop: one counted s_waitcnt vmcnt(6) per k-tile (in P4) retires
-// k-tile t+1 while three half-tiles of k-tile t+2 stay in flight across the raw s_barriers.
-// Hazards (MI355X guide §5 "8-phase template"): RAW - a half-tile is read >= 1 phase after the counted wait +
-// barrier that retired it; WAR - re-staged two phases after its last ds_read, or one phase after when an
-// lgkmcnt before the reading phase's barrier retired the reads (W0: lgkmcnt(8) in P1).
-// ---------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_vptr;
-
-template <int ABL>   // ablation aid: 0 normal, 1 no DMA in the loop, 2 no MFMA, 3 no epilogue
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_pp256_kernel(GemmParams p) {
-    constexpr int HALF = 128 * 128, BUF = 4 * HALF;       // 16 KiB half-tile, 64 KiB k-tile (W0,X0,W1,X1)
-    constexpr int SW0 = 0, SX0 = HALF, SW1 = 2 * HALF, SX1 = 3 * HALF;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 2, wq = wave & 3;               // group (= M half of the tile), N quarter
-    int tile_m, tile_n;
-    tile_of_block<4>((p.M + 255) / 256, p.N / 256, tile_m, tile_n);
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
-    const int nk = p.K / BK;
-
-    // DMA: a wave moves pieces {wave, wave+8} (8 rows x 128 B each) of every half-tile.  Half-tile local row
-    // lr -> tile row:  W_h: (lr>>5)*64 + h*32 + (lr&31)     X_h: (lr>>6)*128 + h*64 + (lr&63)
-    const int prow = lane >> 3, pc = lane & 7;
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
-    int vW[2][2], vX[2][2];                                // [half][piece] byte offsets of this lane's 16 B
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int lr = (wave + 8 * i) * 8 + prow;
-        const int c = pc ^ ((lr >> 1) & 7);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int nr = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
-            const int mr = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);
-            vW[h][i] = nr * p.ldw * 2 + c * 16;
-            vX[h][i] = mr * p.lda * 2 + c * 16;
-        }
-    }
-#define SRH_PP_DMA(rs, vo, kt, buf, slot) { \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(smem + (buf) * BUF + (slot) + wave * 1024), 16, vo[0], (kt) * (BK * 2), 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(smem + (buf) * BUF + (slot) + (wave + 8) * 1024), 16, vo[1], (kt) * (BK * 2), 0, 0); }
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int fkey = (frow >> 1) & 7;
-    int foff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
-    const int wbase = wq * 4096, xbase = g * 8192;
-
-    // prologue: all of k-tile 0, three half-tiles of k-tile 1 (X1(1) is issued by P1 of k-tile 0)
-    SRH_PP_DMA(rsW, vW[0], 0, 0, SW0) SRH_PP_DMA(rsX, vX[0], 0, 0, SX0)
-    SRH_PP_DMA(rsW, vW[1], 0, 0, SW1) SRH_PP_DMA(rsX, vX[1], 0, 0, SX1)
-    if (nk > 1) {
-        SRH_PP_DMA(rsW, vW[0], 1, 1, SW0) SRH_PP_DMA(rsX, vX[0], 1, 1, SX0) SRH_PP_DMA(rsW, vW[1], 1, 1, SW1)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (g == 1) __builtin_amdgcn_s_barrier();              // stagger: group 1 runs one segment behind group 0
-
-    f16x8 fw0[4], fw1[4], fx[2][4];
-#define SRH_PP_RDW(F, buf, slot) { const char* s_ = smem + (buf) * BUF + (slot) + wbase; \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) F[ks] = *reinterpret_cast<const f16x8*>(s_ + foff[ks]); }
-#define SRH_PP_RDX(buf, slot) { const char* s_ = smem + (buf) * BUF + (slot) + xbase; \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { fx[0][ks] = *reinterpret_cast<const f16x8*>(s_ + foff[ks]); \
-                                                        fx[1][ks] = *reinterpret_cast<const f16x8*>(s_ + foff[ks] + 4096); } }
-// The MFMA builtins are pure register operations: neither sched_barrier nor the asm memory clobbers keep the
-// instruction selector from sliding them across the segment barriers.  Pin them through their operands: the
-// fragments become opaque right after the lgkmcnt wait (no MFMA above it) and the accumulators right before
-// the closing barrier (no MFMA below it).
-#define SRH_PP_PIN4(F) { _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(F[ks])); }
-#define SRH_PP_MMA(F, i, j0) { if (ABL != 2) { \
-    SRH_PP_PIN4(F) SRH_PP_PIN4(fx[0]) SRH_PP_PIN4(fx[1]) \
-    __builtin_amdgcn_s_setprio(1); \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { acc[i][j0] = mfma32(F[ks], fx[0][ks], acc[i][j0]); \
-                                                        acc[i][j0 + 1] = mfma32(F[ks], fx[1][ks], acc[i][j0 + 1]); } \
-    asm volatile("" : "+v"(acc[i][j0])); asm volatile("" : "+v"(acc[i][j0 + 1])); \
-    __builtin_amdgcn_s_setprio(0); } else { \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(F[ks]), "v"(fx[0][ks]), "v"(fx[1][ks])); } }
-#define SRH_PP_SEG_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-
-    for (int t = 0; t < nk; ++t) {
-        const int b = t & 1;
-        const bool dma1 = ABL != 1 && t + 1 < nk, dma2 = ABL != 1 && t + 2 < nk;
-        // ---- P1: quadrant (W0, X0)
-        SRH_PP_RDW(fw0, b, SW0)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_PP_RDX(b, SX0)
-        if (dma1) SRH_PP_DMA(rsX, vX[1], t + 1, b ^ 1, SX1)
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 4 W0 reads have returned: W0 may be re-staged in P2
-        SRH_PP_SEG_BARRIER()
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_PP_MMA(fw0, 0, 0)
-        SRH_PP_SEG_BARRIER()
-        // ---- P2: quadrant (W1, X0)
-        SRH_PP_RDW(fw1, b, SW1)
-        if (dma2) SRH_PP_DMA(rsW, vW[0], t + 2, b, SW0)
-        SRH_PP_SEG_BARRIER()
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_PP_MMA(fw1, 1, 0)
-        SRH_PP_SEG_BARRIER()
-        // ---- P3: quadrant (W1, X1)
-        SRH_PP_RDX(b, SX1)
-        if (dma2) SRH_PP_DMA(rsX, vX[0], t + 2, b, SX0)
-        SRH_PP_SEG_BARRIER()
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_PP_MMA(fw1, 1, 2)
-        SRH_PP_SEG_BARRIER()
-        // ---- P4: quadrant (W0, X1); retire k-tile t+1
-        if (dma2) {
-            SRH_PP_DMA(rsW, vW[1], t + 2, b, SW1)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        SRH_PP_SEG_BARRIER()
-        SRH_PP_MMA(fw0, 0, 2)
-        SRH_PP_SEG_BARRIER()
-    }
-    if (g == 0) __builtin_amdgcn_s_barrier();              // re-align the groups
-    __syncthreads();
-    if (ABL == 3) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-        return;
-    }
-    epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + g * 128, n0 + wq * 64, lane);
-    __builtin_amdgcn_wave_barrier();
-    epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + g * 128 + 64, n0 + wq * 64, lane);
-}
-
 // Tile configuration: WN x WM waves, each wave TN x TM MFMA tiles of 32x32 (N = weight rows, M = activation rows)
 //   small: 2x2 waves, 2x2 tiles -> 128x128, 256 threads, 64 KiB LDS, 2 workgroups / CU
 //   big:   4x2 waves, 2x4 tiles -> 256(N) x 256(M), 512 threads, 128 KiB LDS, 1 workgroup / CU
@@ -785,25 +524,18 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.conv_S > 0) return launch_cfg<1, 2, 2, 2, 2>(p, stream);
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;   // tuning aid
     const int variant = p.variant ? p.variant : env_variant;
-    if (variant >= 60 && variant <= 68) return launch_gemm_w192(p, stream, variant - 60);
     if (variant >= 50 && variant <= 57) return launch_gemm_q192(p, stream, variant - 50);
     // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
     static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
     if (variant == 0 && use_q192 && q192_preferred(p)) return launch_gemm_q192(p, stream, 0);
     if (variant == 1) return launch_cfg<0, 2, 2, 2, 2>(p, stream);
     if (variant == 2 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<0, 4, 2, 2, 4>(p, stream);
-    if (false) return (p.N % 256 == 0) ? launch_cfg<0, 4, 2, 2, 4>(p, stream) : -2;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp256_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -819,17 +551,6 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     const bool short_k = p.K <= 256 && !shortk256 && variant < 20;
     if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && !short_k && (fits256 || variant >= 20)) {
         const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
-        if (variant == 30 && p.K >= 128) {   // experimental ring pipeline: measured no faster than the 2-stage kernel
-            hipLaunchKernelGGL(gemm_ring256_kernel, g256, dim3(512), 131072, stream, p);
-            return hipGetLastError() == hipSuccess ? 0 : -3;
-        }
-        if (variant >= 40 && variant <= 43) {
-            if (variant == 40) hipLaunchKernelGGL(gemm_pp256_kernel<0>, g256, dim3(512), 131072, stream, p);
-            if (variant == 41) hipLaunchKernelGGL(gemm_pp256_kernel<1>, g256, dim3(512), 131072, stream, p);
-            if (variant == 42) hipLaunchKernelGGL(gemm_pp256_kernel<2>, g256, dim3(512), 131072, stream, p);
-            if (variant == 43) hipLaunchKernelGGL(gemm_pp256_kernel<3>, g256, dim3(512), 131072, stream, p);
-            return hipGetLastError() == hipSuccess ? 0 : -3;
-        }
         if (variant == 21) hipLaunchKernelGGL(gemm_glds256_kernel<1>, g256, dim3(512), 131072, stream, p);
         else if (variant == 22) hipLaunchKernelGGL(gemm_glds256_kernel<2>, g256, dim3(512), 131072, stream, p);
         else hipLaunchKernelGGL(gemm_glds256_kernel<0>, g256, dim3(512), 131072, stream, p);

@@ -21,9 +21,12 @@
 // phase after it was read; each DMA is issued two phases before the counted s_waitcnt vmcnt(7) that retires it
 // and three phases before it is read (RAW: read >= 1 phase after wait + barrier, one barrier more because the
 // groups are staggered).  LDS: 2 x (W 24 KiB | X0 16 KiB | X1 16 KiB) + 3 bias slots = 136 KiB.
-// Epilogue stores share vmcnt with the DMA loads and may retire out of order with them: every counted wait uses
-// N = the number of younger LOADS only (safe for any store completion order), and each store is issued right
-// after a wait so that it has a full phase to be acknowledged before the next one.
+// Epilogue stores share vmcnt with the DMA loads.  On gfx9-family targets (no separate vscnt) the counter is decremented
+// in ISSUE order for loads and stores alike — LLVM's SIInsertWaitcnts models every pre-gfx10 VMEM access as ONE in-order
+// event class and its own counted waits depend on it — so a counted wait's N = ALL younger VMEM operations, loads and
+// stores (q_wait_vm(7 + nst) below).  Undercounting N would only wait longer; overcounting would read a slab early, which
+// tests/test_gpu_ops.py's q192 cases (bit-repeatable over repeated launches, checked against an f32 reference) would show
+// as sporadic wrong tiles.
 #include <cstdlib>
 #include <type_traits>
 

@@ -30,7 +30,6 @@ int gemm_splitk_factor(const GemmParams& p);   // what launch_gemm would use if 
 bool q192_supported(const GemmParams& p);
 bool q192_preferred(const GemmParams& p);
 int launch_gemm_q192(const GemmParams& p, hipStream_t s, int ablation = 0);
-int launch_gemm_w192(const GemmParams& p, hipStream_t s, int ablation = 0);   // one-wave-per-SIMD variant (gemm_w192.hip)
 
 // Row LayerNorm (biased variance) f32 [M,D] -> fp16 and/or f32; gamma == nullptr => cast only.
 struct NormParams {
@@ -55,23 +54,10 @@ struct PatchParams {
 };
 int launch_patch_im2col(const PatchParams& p, hipStream_t s);
 
-// Decomposed rel-pos bias (K5/K6 bias term): rel[token, head, 0:Wp] = inv_scale * q . Rh[qh, kh],
-// rel[token, head, Wp:2Wp] = inv_scale * q . Rw[qw, kw]   (f32; Wp = win rounded up to 16)
-struct RelPosParams {
-    const f16* qkv = nullptr; int ld = 0;   // [tokens, 3*D]
-    const f16* table_h = nullptr;           // [2*win-1, hd] fp16
-    const f16* table_w = nullptr;
-    float* rel = nullptr;                   // [tokens, heads, 2*Wp]
-    int B = 0, S = 0, heads = 0, hd = 0, win = 0;
-    float inv_scale = 8.f;
-};
-int launch_relpos(const RelPosParams& p, hipStream_t s);
-
 // Windowed / global attention with rel-pos bias; pad tokens are real keys with k = b_k, v = b_v.
 struct AttnParams {
     const f16* qkv = nullptr; int ld = 0;   // [tokens, 3*D]: q | k | v, each head-major
-    const float* rel = nullptr;             // from launch_relpos; nullptr => fused: the kernel derives the bias from table_h / table_w
-    const f16* table_h = nullptr;           // [2*win-1, hd] fp16 rel-pos tables (fused path)
+    const f16* table_h = nullptr;           // [2*win-1, hd] fp16 rel-pos tables: the kernels derive the bias from the unscaled q
     const f16* table_w = nullptr;
     const f16* bias_qkv = nullptr;          // [3*D] fp16 (pad-token k / v rows)
     f16* out = nullptr; int ldo = 0;        // [tokens, D]
@@ -83,19 +69,6 @@ int launch_attention(const AttnParams& p, hipStream_t s);
 // attention_hdx.hip: MFMA attention for head dim 80 on 14x14 windows / the 16x16 global window (ViT-H at 256 px)
 bool attention_hdx_supported(const AttnParams& p);
 int launch_attention_hdx(const AttnParams& p, hipStream_t s);
-
-// map_decoder last stage: ConvT(32->2,k2s2) + sigmoid + quad-tree -> NHWC scatter.
-struct DecodeOutParams {
-    const f16* x = nullptr;      // [B*S*S*64, 32] rows in quad-tree order (px, sub1, sub2, sub3)
-    const float* w = nullptr;    // [8,32]: n = (ky*2+kx)*2 + class
-    const float* bias = nullptr; // [2]
-    int B = 0, S = 0;            // S = tokens per side (P/16)
-    float* logits = nullptr;     // nullable [B,P,P,2]
-    float* scores = nullptr;     // nullable [B,P,P,2]
-    // optional fused scene scatter-add: canvas[(y0+y)*scene_S + x0+x] += score
-    float* canvas_kp = nullptr; float* canvas_road = nullptr; int scene_S = 0; const int* tile_xy = nullptr;
-};
-int launch_decode_out(const DecodeOutParams& p, hipStream_t s);
 
 // last two decoder layers fused (decoder.hip decode_tail_kernel): ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + NHWC scatter
 struct DecodeTailParams {
@@ -139,14 +112,6 @@ struct PairGatherParams {
 };
 int launch_pair_gather(const PairGatherParams& p, hipStream_t s);
 
-struct TopoAttnParams {
-    const f16* qkv = nullptr;       // [nseq*16, 384]
-    const uint8_t* valid = nullptr; // [nseq,16]
-    f16* out = nullptr;             // [nseq*16, 128]
-    int nseq = 0;
-};
-int launch_topo_attention(const TopoAttnParams& p, hipStream_t s);
-
 // fused TopoNet trunk (topo_fused.hip): pair rows -> logits / scores
 struct TopoFusedParams {
     const f16* pair = nullptr; int ld_pair = 320;     // [nseq*16, ld_pair] gathered pair rows (src | tgt | dx dy | 0)
@@ -157,12 +122,5 @@ struct TopoFusedParams {
     float* logits = nullptr; float* scores = nullptr; // [nseq*16], nullable
 };
 int launch_topo_fused(const TopoFusedParams& p, hipStream_t s);
-
-struct TopoOutParams {
-    const float* x = nullptr;       // [rows,128] f32
-    const float* w = nullptr; float b = 0.f;
-    int rows = 0; float* logits = nullptr; float* scores = nullptr;
-};
-int launch_topo_out(const TopoOutParams& p, const float* bias_dev, hipStream_t s);
 
 }  // namespace srh

@@ -109,99 +109,4 @@ int launch_pair_gather(const PairGatherParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// 16-token, 4-head (x32) self-attention with key-padding mask; one wave per sequence,
-// lane = (head, query).  scale = 32^-0.5.  All-invalid sequences attend to every key
-// (model.py:129-130).
-__global__ __launch_bounds__(256) void topo_attention_kernel(TopoAttnParams p) {
-    const int lane = threadIdx.x & 63;
-    const long seq = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (seq >= p.nseq) return;
-    const int h = lane >> 4, qi = lane & 15;
-    const f16* base = p.qkv + seq * 16 * 384;
-    unsigned vmask = 0;
-    for (int j = 0; j < 16; ++j) vmask |= (p.valid[seq * 16 + j] ? 1u : 0u) << j;
-    if (vmask == 0) vmask = 0xffffu;
-    f16x2 q[16];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(base + qi * 384 + h * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 t = src[i];
-            const f16x2* hh = reinterpret_cast<const f16x2*>(&t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q[i * 4 + e] = hh[e];
-        }
-    }
-    float sc[16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint4* src = reinterpret_cast<const uint4*>(base + j * 384 + 128 + h * 32);
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 t = src[i];
-            const f16x2* hh = reinterpret_cast<const f16x2*>(&t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_fdot2(q[i * 4 + e], hh[e], a, false);
-        }
-        a *= 0.17677669529663687f;
-        sc[j] = ((vmask >> j) & 1) ? a : -INFINITY;
-        mx = fmaxf(mx, sc[j]);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
-    const float inv = 1.f / sum;
-    float o[32];
-#pragma unroll
-    for (int d = 0; d < 32; ++d) o[d] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint4* src = reinterpret_cast<const uint4*>(base + j * 384 + 256 + h * 32);
-        const float pj = sc[j] * inv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 t = src[i];
-            const f16* hh = reinterpret_cast<const f16*>(&t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[i * 8 + e] = fmaf(pj, (float)hh[e], o[i * 8 + e]);
-        }
-    }
-    f16* out = p.out + (seq * 16 + qi) * 128 + h * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f16x8 t;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = (f16)o[i * 8 + e];
-        *reinterpret_cast<f16x8*>(out + i * 8) = t;
-    }
-}
-
-int launch_topo_attention(const TopoAttnParams& p, hipStream_t s) {
-    if (p.nseq <= 0) return 0;
-    hipLaunchKernelGGL(topo_attention_kernel, dim3((unsigned)((p.nseq + 3) / 4)), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-// logits = x . w + b ; scores = sigmoid(logits).  One wave per row (128 f32).
-__global__ __launch_bounds__(256) void topo_out_kernel(TopoOutParams p, const float* bias) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
-    const float2 x = *reinterpret_cast<const float2*>(p.x + row * 128 + lane * 2);
-    const float2 w = *reinterpret_cast<const float2*>(p.w + lane * 2);
-    const float v = wave_sum(x.x * w.x + x.y * w.y) + bias[0];
-    if (lane == 0) {
-        if (p.logits) p.logits[row] = v;
-        if (p.scores) p.scores[row] = 1.f / (1.f + expf(-v));
-    }
-}
-
-int launch_topo_out(const TopoOutParams& p, const float* bias_dev, hipStream_t s) {
-    if (p.rows <= 0) return 0;
-    hipLaunchKernelGGL(topo_out_kernel, dim3((unsigned)((p.rows + 3) / 4)), dim3(256), 0, s, p, bias_dev);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
 }  // namespace srh

@@ -183,7 +183,8 @@ def votes_to_edges(uk, sums, cnts, first, n_pts, threshold):
     """inferencer.py:224-228: mean directed score > TOPO_THRESHOLD, as an [E,2] array in the INSERTION order of the
     reference's dict (= order of each key's first vote; `first` from edge_votes / gather_edge_votes).  That order follows the
     per-tile point order, which in the reference is whatever rtree.intersection yields; here tiles list their points by
-    ascending global index (the edge SET does not depend on it — pinned by tests/test_refrun_golden.py)."""
+    ascending global index (the edge SET does not depend on it — pinned by tests/test_refrun_golden.py).  Among EQUIDISTANT
+    neighbours of one source point the slot order is scipy-heap-internal in the reference and distance-then-index here."""
     keep = (sums / np.maximum(cnts, 1.0)) > threshold
     k = uk[keep][np.argsort(first[keep], kind="stable")]
     return np.stack([k // n_pts, k % n_pts], axis=1).reshape(-1, 2)

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .sam_decoder import MaskDecoder, PromptEncoder, TwoWayTransformer
 from .sam_encoder import ARCH, ImageEncoderViT, LayerNorm2d
 
 
@@ -84,7 +85,7 @@ class TopoNet(nn.Module):  # model.py:61-148
 
 
 class SAMRoadOracle(nn.Module):
-    """model.py:190-300 (inference-relevant part), USE_SAM_DECODER False."""
+    """model.py:190-300 (inference-relevant part): naive map_decoder, or SAM's MaskDecoder when USE_SAM_DECODER."""
 
     def __init__(self, config):
         super().__init__()
@@ -92,8 +93,6 @@ class SAMRoadOracle(nn.Module):
         assert config.SAM_VERSION in {"vit_b", "vit_l", "vit_h"}
         if config.NO_SAM:
             raise NotImplementedError("NO_SAM ablation (model.py:232-242)")
-        if config.USE_SAM_DECODER:
-            raise NotImplementedError("SAM MaskDecoder branch: SURVEY §8f rank 4")
         arch = dict(ARCH[config.SAM_VERSION])
         # test hook (not a reference key; absent => falsy => ignored)
         if config.ENCODER_DEPTH:
@@ -105,11 +104,20 @@ class SAMRoadOracle(nn.Module):
         self.image_encoder = ImageEncoderViT(img_size=config.PATCH_SIZE, patch_size=16,
                                              window_size=14, out_chans=256, **arch)
         act = nn.GELU
-        self.map_decoder = nn.Sequential(  # model.py:286-295
-            nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2), LayerNorm2d(128), act(),
-            nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2), act(),
-            nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2), act(),
-            nn.ConvTranspose2d(32, 2, kernel_size=2, stride=2))
+        if config.USE_SAM_DECODER:  # model.py:260-282
+            s = config.PATCH_SIZE // 16
+            self.prompt_encoder = PromptEncoder(embed_dim=256, image_embedding_size=(s, s),
+                                                input_image_size=(config.PATCH_SIZE, config.PATCH_SIZE), mask_in_chans=16)
+            self.mask_decoder = MaskDecoder(
+                num_multimask_outputs=2,
+                transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+                transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+        else:
+            self.map_decoder = nn.Sequential(  # model.py:286-295
+                nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2), LayerNorm2d(128), act(),
+                nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2), act(),
+                nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2), act(),
+                nn.ConvTranspose2d(32, 2, kernel_size=2, stride=2))
         self.bilinear_sampler = BilinearSampler(config)
         self.topo_net = TopoNet(config, 256)
 
@@ -118,10 +126,21 @@ class SAMRoadOracle(nn.Module):
         x = (x - self.pixel_mean) / self.pixel_std  # model.py:465-467
         return self.image_encoder(x)
 
+    def _decode(self, emb):
+        """model.py:425-446 / :470-491 -> mask logits [B,2,P,P]."""
+        if not self.config.USE_SAM_DECODER:
+            return self.map_decoder(emb)
+        sparse, dense = self.prompt_encoder(points=None, boxes=None, masks=None)
+        low_res, _ = self.mask_decoder(image_embeddings=emb, image_pe=self.prompt_encoder.get_dense_pe(),
+                                       sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                                       multimask_output=True)
+        return F.interpolate(low_res, (self.image_encoder.img_size, self.image_encoder.img_size), mode="bilinear",
+                             align_corners=False)
+
     @torch.no_grad()
     def forward(self, rgb, graph_points, pairs, valid):  # model.py:414-457
         emb = self._encode(rgb)
-        mask_logits = self.map_decoder(emb)
+        mask_logits = self._decode(emb)
         mask_scores = torch.sigmoid(mask_logits)
         feats = self.bilinear_sampler(emb, graph_points)
         topo_logits, topo_scores = self.topo_net(graph_points, feats, pairs, valid)
@@ -131,7 +150,7 @@ class SAMRoadOracle(nn.Module):
     @torch.no_grad()
     def infer_masks_and_img_features(self, rgb):  # model.py:459-495
         emb = self._encode(rgb)
-        mask_scores = torch.sigmoid(self.map_decoder(emb))
+        mask_scores = torch.sigmoid(self._decode(emb))
         return mask_scores.permute(0, 2, 3, 1), emb
 
     @torch.no_grad()

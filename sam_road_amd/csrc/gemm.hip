@@ -524,7 +524,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.conv_S > 0) return launch_cfg<1, 2, 2, 2, 2>(p, stream);
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;   // tuning aid
     const int variant = p.variant ? p.variant : env_variant;
-    if (variant >= 50 && variant <= 57) return launch_gemm_q192(p, stream, variant - 50);
+    if (variant >= 50 && variant <= 59) return launch_gemm_q192(p, stream, variant - 50);
     // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
     static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
     if (variant == 0 && use_q192 && q192_preferred(p)) return launch_gemm_q192(p, stream, 0);

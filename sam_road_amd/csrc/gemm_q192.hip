@@ -77,7 +77,8 @@ __device__ __forceinline__ void q_wait_vm(int n) {      // wave-uniform n
 }
 
 // SCH 0: two barriers per phase, the groups' read and MFMA segments strictly paired (the MI355X guide's template).
-// SCH 1: one barrier per phase, the groups run their read / MFMA segments in opposite order (see the loop).
+// SCH 1: one barrier per phase, the groups run their read / MFMA segments in opposite order (see the loop; measured slower).
+// SCH 2 / 3: SCH 0 with sched_group_barrier weaving 3 / 2 epilogue VALU into every MFMA gap (SCH 3 is fc1's default).
 template <int ABL, int ACT, bool BIAS, int SCH>   // ABL ablation aid: 0 normal, 1 no epilogue stores, 2 no MFMA, 3 segment timing, 4 no DMA in the loop; ACT 0 none / 1 GELU / 2 ReLU
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_q192_kernel(GemmParams p) {
@@ -195,6 +196,10 @@ void gemm_q192_kernel(GemmParams p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[nt][(h) * 4 + mt] = mfma16(wf[nt][ks], xf[mt][ks], acc[nt][(h) * 4 + mt]); \
+    /* SCH 2: tell the scheduler to WEAVE the epilogue VALU into the MFMA stream (left alone hipcc emits the ~50 GELU VALU as */ \
+    /* two or three long runs and then 19 MFMAs back to back: the matrix pipe idles during the runs) */ \
+    if (SCH >= 2) { _Pragma("unroll") for (int m_ = 0; m_ < 24; ++m_) { \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, ACT == 1 ? (SCH == 2 ? 3 : 2) : 1, 0); } } \
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][(h) * 4 + mt])); \
     asm volatile("" : "+v"(rpend)); \
@@ -237,7 +242,7 @@ void gemm_q192_kernel(GemmParams p) {
             for (int kk = 0; kk < 12; ++kk, --s_left) {
                 const int b = kk & 1;            // == global step parity (nk and kb are even)
                 const bool more1 = s_left > 1, more2 = s_left > 2;
-              if (SCH == 0) {
+              if (SCH != 1) {
                 // ================= P0: W x X0          (epilogue step I = 2 kk: bias read here, math inside the MFMA
                 f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};   //  segment, store in the next ds_read segment)
                 Q_EPI_BIAS(2 * kk, bias4)
@@ -432,6 +437,8 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<4, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<5, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         attr_set = true;
     }
     if (ablation == 1) hipLaunchKernelGGL((gemm_q192_kernel<1, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
@@ -441,6 +448,11 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
     else if (ablation == 5) hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else if (ablation == 6) hipLaunchKernelGGL((gemm_q192_kernel<4, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else if (ablation == 7) hipLaunchKernelGGL((gemm_q192_kernel<5, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else if (ablation == 8) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 2>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    else if (ablation == 9) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    // default: the GELU layer (fc1) takes the woven schedule (SCH 3: two epilogue VALU per MFMA gap; measured -3 % on fc1,
+    // profiles/r02_gemm_q192_weave.txt), the layers without activation gain nothing from it
+    else if (ACT == 1) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
 }
 

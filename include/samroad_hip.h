@@ -26,12 +26,12 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 1
+#define SRH_ABI_VERSION 2
 
 typedef enum {
     SRH_OK = 0,
     SRH_ERR_BAD_ARG = -1,      /* null pointer, bad dtype code, bad shape */
-    SRH_ERR_UNSUPPORTED = -2,  /* configuration not built (e.g. head_dim other than 64 / 80, USE_SAM_DECODER) */
+    SRH_ERR_UNSUPPORTED = -2,  /* configuration not built (e.g. head_dim other than 64 / 80) */
     SRH_ERR_HIP = -3,          /* HIP runtime error (text in srh_last_error) */
     SRH_ERR_MISSING_WEIGHT = -4,
     SRH_ERR_NO_DEVICE = -5
@@ -52,6 +52,7 @@ typedef struct {
     int32_t global_attn_indexes[8];
     int32_t window_size;        /* 14 */
     int32_t toponet_version;    /* 0 'normal' (and 'no_tgt_features', App. D.7), 1 'no_offset', 2 'no_transformer' */
+    int32_t use_sam_decoder;    /* config.USE_SAM_DECODER (model.py:260-282): 0 = naive map_decoder, 1 = SAM PromptEncoder + MaskDecoder */
 } srh_model_cfg;
 
 /* One state_dict entry (SURVEY.md Appendix A names), f32, contiguous. */

@@ -20,7 +20,7 @@ class SrhError(RuntimeError):
 class ModelCfg(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
                 ("patch_size", C.c_int32), ("n_global", C.c_int32), ("global_attn_indexes", C.c_int32 * 8),
-                ("window_size", C.c_int32), ("toponet_version", C.c_int32)]
+                ("window_size", C.c_int32), ("toponet_version", C.c_int32), ("use_sam_decoder", C.c_int32)]
 
 
 class NamedTensor(C.Structure):
@@ -75,7 +75,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.srh_abi_version() != 1:
+    if lib.srh_abi_version() != 2:
         raise SrhError("libsamroad_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -44,6 +44,8 @@ struct srh_ctx {
     // encoder / decoder workspace
     DevBuf a0, x, xn16, delta16, qkv16, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16;
     DevBuf scores_ws, emb_ws, counter, split_ws;
+    // SAM MaskDecoder branch workspace
+    DevBuf sd_keys, sd_keys16, sd_k16, sd_v16, sd_a16, sd_u0, sd_u0_16, sd_u1_16, sd_low, sd_tok;
     // toponet workspace
     DevBuf t_feat16, t_pf16, t_pair16;
     // profiling
@@ -59,8 +61,25 @@ struct BlockW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
     f16 *qkv_w, *qkv_b16, *rel_h, *rel_w, *proj_w, *fc1_w, *fc2_w;
 };
+// SAM MaskDecoder branch (USE_SAM_DECODER; sam_decoder.hip).  Attention a: image-side projection weights fp16 + the
+// positional term pe . W^T precomputed at pack time; token-side weights f32.
+struct SdAttnW { float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b; };                        // token-side self attention (f32)
+struct SdT2IW { float *q_w, *q_b, *o_w, *o_b; f16 *k_w, *v_w; float *k_b, *v_b, *k_pos; };     // token -> image
+struct SdI2TW { f16 *q_w, *o_w; float *q_b, *o_b, *q_pos, *k_w, *k_b, *v_w, *v_b; };           // image -> token
+struct SdLayerW {
+    SdAttnW self; SdT2IW t2i; SdI2TW i2t;
+    float *n1_g, *n1_b, *n2_g, *n2_b, *n3_g, *n3_b, *n4_g, *n4_b, *l1_w, *l1_b, *l2_w, *l2_b;
+};
+struct SdW {
+    float *no_mask, *tokens;                 // [256], [4,256] = iou_token | mask_tokens
+    SdLayerW layer[2];
+    SdT2IW fin; float *nf_g, *nf_b;
+    f16 *up0_w, *up1_w; float *up0_b, *up_ln_g, *up_ln_b, *up1_b;
+    float *hy_w[3][3], *hy_b[3][3];
+};
 struct srh_weights {
     srh_model_cfg cfg;
+    SdW sd;
     int S = 0, D = 0, heads = 0, hd = 0;
     void* arena = nullptr;
     f16* patch_w; float* patch_b; float* pos;
@@ -143,6 +162,8 @@ extern "C" void srh_ctx_destroy(srh_ctx* c) {
     hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->delta16, &c->qkv16, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
                       &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
+                      &c->sd_keys, &c->sd_keys16, &c->sd_k16, &c->sd_v16, &c->sd_a16, &c->sd_u0, &c->sd_u0_16, &c->sd_u1_16,
+                      &c->sd_low, &c->sd_tok,
                       &c->t_feat16, &c->t_pf16, &c->t_pair16};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -268,6 +289,121 @@ static void pack_topo_fused(Packer& pk, srh_weights* w, int nl) {
     pk.slot(&w->tp_stream, soff);
     pk.slot(&w->tp_params, poff);
 }
+
+// SAM MaskDecoder branch: prompt_encoder.* / mask_decoder.* (fork key names; oracle/sam_decoder.py).  The random-Fourier
+// positional encoding of the S x S grid (get_dense_pe) is constant: pe and every pe . W^T the decoder needs are computed here.
+static void pack_sam_decoder(Packer& pk, srh_weights* w) {
+    const int S = w->S, HW = S * S;
+    SdW& d = w->sd;
+    const std::string PE = "prompt_encoder.", MD = "mask_decoder.", TR = "mask_decoder.transformer.";
+    pk.put_f32(&d.no_mask, PE + "no_mask_embed.weight", 256);
+    // parameters the no-prompt path never reads must still be present in a checkpoint of this branch
+    for (const char* k : {"point_embeddings.0.weight", "point_embeddings.1.weight", "point_embeddings.2.weight",
+                          "point_embeddings.3.weight", "not_a_point_embed.weight"}) (void)pk.get(PE + k, 256);
+    {
+        const float* it = pk.get(MD + "iou_token.weight", 256);
+        std::vector<float> tok(4 * 256, 0.f);
+        if (it) memcpy(tok.data(), it, 256 * 4);
+        const float* mt = pk.get(MD + "mask_tokens.weight", 3 * 256);
+        if (mt) memcpy(tok.data() + 256, mt, 3 * 256 * 4);
+        const size_t off = pk.alloc(4 * 256 * 4);
+        memcpy(pk.host.data() + off, tok.data(), 4 * 256 * 4);
+        pk.slot(&d.tokens, off);
+    }
+    // pe[y*S + x][c]: coords ((x + .5)/S, (y + .5)/S) -> 2c - 1 -> @ G[2,128] -> 2 pi -> sin | cos
+    std::vector<float> pe((size_t)HW * 256, 0.f);
+    {
+        const float* G = pk.get(PE + "pe_layer.positional_encoding_gaussian_matrix", 2 * 128);
+        if (G)
+            for (int y = 0; y < S; ++y)
+                for (int x = 0; x < S; ++x) {
+                    const float cx = 2.f * (((float)x + 0.5f) / (float)S) - 1.f, cy = 2.f * (((float)y + 0.5f) / (float)S) - 1.f;
+                    for (int j = 0; j < 128; ++j) {
+                        const float a = 2.f * 3.14159265358979323846f * (cx * G[j] + cy * G[128 + j]);
+                        pe[((size_t)y * S + x) * 256 + j] = sinf(a);
+                        pe[((size_t)y * S + x) * 256 + 128 + j] = cosf(a);
+                    }
+                }
+    }
+    auto put_pos = [&](float** dst, const float* W) {      // pe [HW,256] . W[128,256]^T -> [HW,128] f32
+        const size_t off = pk.alloc((size_t)HW * 128 * 4);
+        if (W) {
+            float* o = reinterpret_cast<float*>(pk.host.data() + off);
+            for (int t = 0; t < HW; ++t)
+                for (int n = 0; n < 128; ++n) {
+                    double a = 0.0;
+                    for (int k = 0; k < 256; ++k) a += (double)pe[(size_t)t * 256 + k] * W[(size_t)n * 256 + k];
+                    o[(size_t)t * 128 + n] = (float)a;
+                }
+        }
+        pk.slot(dst, off);
+    };
+    auto put_t2i = [&](SdT2IW& a, const std::string& base) {
+        pk.put_f32(&a.q_w, base + "q_proj.weight", 128 * 256); pk.put_f32(&a.q_b, base + "q_proj.bias", 128);
+        pk.put_f16_same(&a.k_w, base + "k_proj.weight", 128 * 256); pk.put_f32(&a.k_b, base + "k_proj.bias", 128);
+        pk.put_f16_same(&a.v_w, base + "v_proj.weight", 128 * 256); pk.put_f32(&a.v_b, base + "v_proj.bias", 128);
+        pk.put_f32(&a.o_w, base + "out_proj.weight", 256 * 128); pk.put_f32(&a.o_b, base + "out_proj.bias", 256);
+        std::vector<float> kw(128 * 256);
+        const float* src = pk.get(base + "k_proj.weight", 128 * 256);
+        if (src) memcpy(kw.data(), src, kw.size() * 4);      // get() may reuse its staging buffer: copy before the next get
+        put_pos(&a.k_pos, src ? kw.data() : nullptr);
+    };
+    auto put_i2t = [&](SdI2TW& a, const std::string& base) {
+        pk.put_f16_same(&a.q_w, base + "q_proj.weight", 128 * 256); pk.put_f32(&a.q_b, base + "q_proj.bias", 128);
+        pk.put_f32(&a.k_w, base + "k_proj.weight", 128 * 256); pk.put_f32(&a.k_b, base + "k_proj.bias", 128);
+        pk.put_f32(&a.v_w, base + "v_proj.weight", 128 * 256); pk.put_f32(&a.v_b, base + "v_proj.bias", 128);
+        pk.put_f16_same(&a.o_w, base + "out_proj.weight", 256 * 128); pk.put_f32(&a.o_b, base + "out_proj.bias", 256);
+        std::vector<float> qw(128 * 256);
+        const float* src = pk.get(base + "q_proj.weight", 128 * 256);
+        if (src) memcpy(qw.data(), src, qw.size() * 4);
+        put_pos(&a.q_pos, src ? qw.data() : nullptr);
+    };
+    for (int l = 0; l < 2; ++l) {
+        SdLayerW& L = d.layer[l];
+        const std::string B_ = TR + "layers." + std::to_string(l) + ".";
+        pk.put_f32(&L.self.q_w, B_ + "self_attn.q_proj.weight", 256 * 256); pk.put_f32(&L.self.q_b, B_ + "self_attn.q_proj.bias", 256);
+        pk.put_f32(&L.self.k_w, B_ + "self_attn.k_proj.weight", 256 * 256); pk.put_f32(&L.self.k_b, B_ + "self_attn.k_proj.bias", 256);
+        pk.put_f32(&L.self.v_w, B_ + "self_attn.v_proj.weight", 256 * 256); pk.put_f32(&L.self.v_b, B_ + "self_attn.v_proj.bias", 256);
+        pk.put_f32(&L.self.o_w, B_ + "self_attn.out_proj.weight", 256 * 256); pk.put_f32(&L.self.o_b, B_ + "self_attn.out_proj.bias", 256);
+        put_t2i(L.t2i, B_ + "cross_attn_token_to_image.");
+        put_i2t(L.i2t, B_ + "cross_attn_image_to_token.");
+        pk.put_f32(&L.n1_g, B_ + "norm1.weight", 256); pk.put_f32(&L.n1_b, B_ + "norm1.bias", 256);
+        pk.put_f32(&L.n2_g, B_ + "norm2.weight", 256); pk.put_f32(&L.n2_b, B_ + "norm2.bias", 256);
+        pk.put_f32(&L.n3_g, B_ + "norm3.weight", 256); pk.put_f32(&L.n3_b, B_ + "norm3.bias", 256);
+        pk.put_f32(&L.n4_g, B_ + "norm4.weight", 256); pk.put_f32(&L.n4_b, B_ + "norm4.bias", 256);
+        pk.put_f32(&L.l1_w, B_ + "mlp.lin1.weight", 2048 * 256); pk.put_f32(&L.l1_b, B_ + "mlp.lin1.bias", 2048);
+        pk.put_f32(&L.l2_w, B_ + "mlp.lin2.weight", 256 * 2048); pk.put_f32(&L.l2_b, B_ + "mlp.lin2.bias", 256);
+    }
+    put_t2i(d.fin, TR + "final_attn_token_to_image.");
+    pk.put_f32(&d.nf_g, TR + "norm_final_attn.weight", 256); pk.put_f32(&d.nf_b, TR + "norm_final_attn.bias", 256);
+    // output_upscaling: ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM weight [n = (ky*2+kx)*Cout + co][ci], bias replicated x4
+    auto convt = [&](f16** dst, float** bdst, const std::string& idx, int cin, int cout) {
+        pk.put_f16(dst, MD + "output_upscaling." + idx + ".weight", (size_t)cin * cout * 4, (size_t)4 * cout * cin,
+                   [cin, cout](size_t i) {
+                       const size_t nidx = i / cin, ci = i % cin, sub = nidx / cout, co = nidx % cout;
+                       return (long)((ci * cout + co) * 4 + sub);
+                   });
+        const float* bsrc = pk.get(MD + "output_upscaling." + idx + ".bias", cout);
+        const size_t off = pk.alloc((size_t)4 * cout * 4);
+        if (bsrc)
+            for (int r = 0; r < 4; ++r) memcpy(pk.host.data() + off + (size_t)r * cout * 4, bsrc, (size_t)cout * 4);
+        pk.slot(bdst, off);
+    };
+    convt(&d.up0_w, &d.up0_b, "0", 256, 64);
+    pk.put_f32(&d.up_ln_g, MD + "output_upscaling.1.weight", 64); pk.put_f32(&d.up_ln_b, MD + "output_upscaling.1.bias", 64);
+    convt(&d.up1_w, &d.up1_b, "3", 64, 32);
+    for (int i = 0; i < 3; ++i)
+        for (int l = 0; l < 3; ++l) {
+            const std::string H = MD + "output_hypernetworks_mlps." + std::to_string(i) + ".layers." + std::to_string(l) + ".";
+            const int out = l == 2 ? 32 : 256;
+            pk.put_f32(&d.hy_w[i][l], H + "weight", (size_t)out * 256); pk.put_f32(&d.hy_b[i][l], H + "bias", out);
+        }
+    // iou_prediction_head: its output is discarded by the reference (model.py:430 `low_res_logits, iou_predictions`); only presence is checked
+    for (int l = 0; l < 3; ++l) {
+        const std::string H = MD + "iou_prediction_head.layers." + std::to_string(l) + ".";
+        (void)pk.get(H + "weight", (size_t)(l == 2 ? 3 : 256) * 256); (void)pk.get(H + "bias", l == 2 ? 3 : 256);
+    }
+}
 }  // namespace
 
 extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
@@ -333,34 +469,38 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
     pk.put_f32(&w->neck3_g, E + "neck.3.weight", 256);
     pk.put_f32(&w->neck3_b, E + "neck.3.bias", 256);
 
-    // map_decoder: ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM weight [n = (ky*2+kx)*Cout + co][ci]
-    auto convt = [&](f16** dst, float** bdst, const std::string& idx, int cin, int cout) {
-        pk.put_f16(dst, "map_decoder." + idx + ".weight", (size_t)cin * cout * 4, (size_t)4 * cout * cin,
-                   [cin, cout](size_t i) {
-                       const size_t nidx = i / cin, ci = i % cin, sub = nidx / cout, co = nidx % cout;
-                       return (long)((ci * cout + co) * 4 + sub);
-                   });
-        const float* bsrc = pk.get("map_decoder." + idx + ".bias", cout);
-        const size_t off = pk.alloc((size_t)4 * cout * 4);
-        if (bsrc)
-            for (int r = 0; r < 4; ++r) memcpy(pk.host.data() + off + (size_t)r * cout * 4, bsrc, (size_t)cout * 4);
-        pk.slot(bdst, off);
-    };
-    convt(&w->dec0_w, &w->dec0_b, "0", 256, 128);
-    pk.put_f32(&w->dec1_g, "map_decoder.1.weight", 128);
-    pk.put_f32(&w->dec1_b, "map_decoder.1.bias", 128);
-    convt(&w->dec3_w, &w->dec3_b, "3", 128, 64);
-    convt(&w->dec5_w, &w->dec5_b, "5", 64, 32);
-    {
-        const float* src = pk.get("map_decoder.7.weight", 32 * 2 * 4);
-        const size_t off = pk.alloc(8 * 32 * 4);
-        if (src) {
-            float* o = reinterpret_cast<float*>(pk.host.data() + off);
-            for (int nn = 0; nn < 8; ++nn)
-                for (int ci = 0; ci < 32; ++ci) o[nn * 32 + ci] = src[(ci * 2 + (nn & 1)) * 4 + (nn >> 1)];
+    if (cfg->use_sam_decoder) {
+        pack_sam_decoder(pk, w);
+    } else {
+        // map_decoder: ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM weight [n = (ky*2+kx)*Cout + co][ci]
+        auto convt = [&](f16** dst, float** bdst, const std::string& idx, int cin, int cout) {
+            pk.put_f16(dst, "map_decoder." + idx + ".weight", (size_t)cin * cout * 4, (size_t)4 * cout * cin,
+                       [cin, cout](size_t i) {
+                           const size_t nidx = i / cin, ci = i % cin, sub = nidx / cout, co = nidx % cout;
+                           return (long)((ci * cout + co) * 4 + sub);
+                       });
+            const float* bsrc = pk.get("map_decoder." + idx + ".bias", cout);
+            const size_t off = pk.alloc((size_t)4 * cout * 4);
+            if (bsrc)
+                for (int r = 0; r < 4; ++r) memcpy(pk.host.data() + off + (size_t)r * cout * 4, bsrc, (size_t)cout * 4);
+            pk.slot(bdst, off);
+        };
+        convt(&w->dec0_w, &w->dec0_b, "0", 256, 128);
+        pk.put_f32(&w->dec1_g, "map_decoder.1.weight", 128);
+        pk.put_f32(&w->dec1_b, "map_decoder.1.bias", 128);
+        convt(&w->dec3_w, &w->dec3_b, "3", 128, 64);
+        convt(&w->dec5_w, &w->dec5_b, "5", 64, 32);
+        {
+            const float* src = pk.get("map_decoder.7.weight", 32 * 2 * 4);
+            const size_t off = pk.alloc(8 * 32 * 4);
+            if (src) {
+                float* o = reinterpret_cast<float*>(pk.host.data() + off);
+                for (int nn = 0; nn < 8; ++nn)
+                    for (int ci = 0; ci < 32; ++ci) o[nn * 32 + ci] = src[(ci * 2 + (nn & 1)) * 4 + (nn >> 1)];
+            }
+            pk.slot(&w->dec7_w, off);
+            pk.put_f32(&w->dec7_b, "map_decoder.7.bias", 2);
         }
-        pk.slot(&w->dec7_w, off);
-        pk.put_f32(&w->dec7_b, "map_decoder.7.bias", 2);
     }
 
     // TopoNet
@@ -423,6 +563,103 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
 #define TRY(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
 #define TRYK(c, cls, fl, by, s, call) do { const int rc_ = run(c, cls, fl, by, s, [&] { return (call); }); \
     if (rc_) return fail(c, rc_ == -2 ? SRH_ERR_UNSUPPORTED : SRH_ERR_HIP, std::string(cls) + ": kernel launch failed"); } while (0)
+
+// ---- SAM MaskDecoder branch (model.py:426-443 / :471-488; kernels in sam_decoder.hip, semantics in oracle/sam_decoder.py) ----
+static int sam_decode(srh_ctx* c, const srh_weights* w, int B, const float* emb, float* logits, float* scores, hipStream_t s) {
+    const int S = w->S, HW = S * S, R = B * 4, P = w->cfg.patch_size;
+    const size_t T = (size_t)B * HW;
+    const SdW& d = w->sd;
+    int rc = 0;
+    rc |= c->sd_keys.ensure(T * 256 * 4);  rc |= c->sd_keys16.ensure(T * 256 * 2);
+    rc |= c->sd_k16.ensure(T * 128 * 2);   rc |= c->sd_v16.ensure(T * 128 * 2);  rc |= c->sd_a16.ensure(T * 128 * 2);
+    rc |= c->sd_u0.ensure(T * 256 * 4);    rc |= c->sd_u0_16.ensure(T * 256 * 2); rc |= c->sd_u1_16.ensure(T * 4 * 128 * 2);
+    rc |= c->sd_low.ensure((size_t)B * 2 * 16 * HW * 4);
+    rc |= c->sd_tok.ensure((size_t)R * (256 * 8 + 2048 + 128 * 4) * 4 + (size_t)B * 3 * (256 * 2 + 32) * 4);
+    if (rc) return fail(c, SRH_ERR_HIP, "SAM decoder workspace allocation failed");
+    float* keys = c->sd_keys.as<float>();
+    f16* keys16 = c->sd_keys16.as<f16>();
+    // token-side scratch (f32): q (queries), t0..t6 temporaries [R,256], h [R,2048], small [R,128] x 4, hyper
+    float* tb = c->sd_tok.as<float>();
+    float* q = tb;              float* t0 = tb + (size_t)R * 256; float* t1 = t0 + (size_t)R * 256; float* t2 = t1 + (size_t)R * 256;
+    float* t3 = t2 + (size_t)R * 256; float* qn = t3 + (size_t)R * 256;   /* qn, qn+R*256: two more [R,256] */
+    float* hid = tb + (size_t)R * 256 * 8;
+    float* s0 = hid + (size_t)R * 2048; float* s1 = s0 + (size_t)R * 128; float* s2 = s1 + (size_t)R * 128; float* s3 = s2 + (size_t)R * 128;
+    float* hy0 = s3 + (size_t)R * 128; float* hy1 = hy0 + (size_t)B * 3 * 256; float* hyper = hy1 + (size_t)B * 3 * 256;
+
+    auto lin = [&](const float* x, int ldx, const float* xadd, int add_rows, const float* W, const float* b, int rows, int N, int K,
+                   int act, float* y, int ldy) -> int {
+        SdLinearParams lp;
+        lp.x = x; lp.ldx = ldx; lp.xadd = xadd; lp.add_rows = add_rows; lp.W = W; lp.b = b; lp.rows = rows; lp.N = N; lp.K = K;
+        lp.act = act; lp.y = y; lp.ldy = ldy;
+        return launch_sd_tok_linear(lp, s);
+    };
+    auto img_gemm = [&](const char* cls, const f16* A, int K, const f16* W, int N, const float* bias, const float* pos,
+                        const float* resid, int act, float* o32, f16* o16, size_t rows) -> int {
+        GemmParams g;
+        g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = (int)rows; g.N = N; g.K = K; g.bias = bias;
+        g.pos = pos; g.pos_rows = HW; g.resid = resid; g.ldr = N; g.act = act;
+        g.out_f32 = o32; g.ldc = N; g.out_f16 = o16; g.ldc16 = N;
+        return gemm(c, cls, g, s);
+    };
+    // token -> image attention + residual + LayerNorm on the tokens: q <- LN(q + attn((q + pe_tok) Wq, (keys + pe) Wk, keys Wv) Wo)
+    auto t2i = [&](const SdT2IW& a, const float* ng, const float* nb) -> int {
+        TRY(img_gemm("sd_gemm", keys16, 256, a.k_w, 128, a.k_b, a.k_pos, nullptr, 0, nullptr, c->sd_k16.as<f16>(), T));
+        TRY(img_gemm("sd_gemm", keys16, 256, a.v_w, 128, a.v_b, nullptr, nullptr, 0, nullptr, c->sd_v16.as<f16>(), T));
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, d.tokens, 4, a.q_w, a.q_b, R, 128, 256, 0, s0, 128));
+        TRYK(c, "sd_attn", 0, 0, s, launch_sd_t2i_attn(s0, c->sd_k16.as<f16>(), c->sd_v16.as<f16>(), s1, B, HW, s));
+        TRYK(c, "sd_token", 0, 0, s, lin(s1, 128, nullptr, 1, a.o_w, a.o_b, R, 256, 128, 0, t0, 256));
+        TRYK(c, "sd_token", 0, 0, s, launch_sd_tok_ln(q, t0, ng, nb, q, R, s));
+        return 0;
+    };
+
+    TRYK(c, "sd_prep", 0, (double)T * 256 * 10, s, launch_sd_add_channel(emb, d.no_mask, keys, keys16, T, s));
+    // queries = the 4 output tokens, identical for every tile
+    for (int b = 0; b < B; ++b)
+        if (hipMemcpyAsync(q + (size_t)b * 1024, d.tokens, 4 * 256 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(c, SRH_ERR_HIP, "token broadcast failed");
+    for (int l = 0; l < 2; ++l) {
+        const SdLayerW& L = d.layer[l];
+        // (1) self attention of the tokens; layer 0 skips the positional term and REPLACES the queries (skip_first_layer_pe)
+        const float* pe_tok = l == 0 ? nullptr : d.tokens;
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, pe_tok, 4, L.self.q_w, L.self.q_b, R, 256, 256, 0, t0, 256));
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, pe_tok, 4, L.self.k_w, L.self.k_b, R, 256, 256, 0, t1, 256));
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, nullptr, 1, L.self.v_w, L.self.v_b, R, 256, 256, 0, t2, 256));
+        TRYK(c, "sd_attn", 0, 0, s, launch_sd_tok_selfattn(t0, t1, t2, t3, B, s));
+        TRYK(c, "sd_token", 0, 0, s, lin(t3, 256, nullptr, 1, L.self.o_w, L.self.o_b, R, 256, 256, 0, t0, 256));
+        TRYK(c, "sd_token", 0, 0, s, launch_sd_tok_ln(t0, l == 0 ? nullptr : q, L.n1_g, L.n1_b, q, R, s));
+        // (2) tokens attend to the image
+        TRY(t2i(L.t2i, L.n2_g, L.n2_b));
+        // (3) token MLP
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, nullptr, 1, L.l1_w, L.l1_b, R, 2048, 256, 2, hid, 2048));
+        TRYK(c, "sd_token", 0, 0, s, lin(hid, 2048, nullptr, 1, L.l2_w, L.l2_b, R, 256, 2048, 0, t0, 256));
+        TRYK(c, "sd_token", 0, 0, s, launch_sd_tok_ln(q, t0, L.n3_g, L.n3_b, q, R, s));
+        // (4) image attends to the tokens: keys <- LN(keys + attn((keys + pe) Wq, (q + pe_tok) Wk, q Wv) Wo)
+        TRY(img_gemm("sd_gemm", keys16, 256, L.i2t.q_w, 128, L.i2t.q_b, L.i2t.q_pos, nullptr, 0, nullptr, c->sd_k16.as<f16>(), T));
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, d.tokens, 4, L.i2t.k_w, L.i2t.k_b, R, 128, 256, 0, s2, 128));
+        TRYK(c, "sd_token", 0, 0, s, lin(q, 256, nullptr, 1, L.i2t.v_w, L.i2t.v_b, R, 128, 256, 0, s3, 128));
+        TRYK(c, "sd_attn", 0, 0, s, launch_sd_i2t_attn(c->sd_k16.as<f16>(), s2, s3, c->sd_a16.as<f16>(), B, HW, s));
+        TRY(img_gemm("sd_gemm", c->sd_a16.as<f16>(), 128, L.i2t.o_w, 256, L.i2t.o_b, nullptr, keys, 0, c->sd_u0.as<float>(), nullptr, T));
+        NormParams ln;
+        ln.x = c->sd_u0.as<float>(); ln.M = (int)T; ln.D = 256; ln.eps = 1e-5f; ln.gamma = L.n4_g; ln.beta = L.n4_b;
+        ln.out_f32 = keys; ln.out_f16 = keys16;
+        TRYK(c, "layernorm", 0, (double)T * 256 * 10, s, launch_layernorm(ln, s));
+    }
+    TRY(t2i(d.fin, d.nf_g, d.nf_b));
+    // output_upscaling: ConvT(256 -> 64) -> LayerNorm2d(64) -> GELU -> ConvT(64 -> 32) -> GELU, rows in quad-tree order
+    TRY(img_gemm("sd_gemm", keys16, 256, d.up0_w, 256, d.up0_b, nullptr, nullptr, 0, c->sd_u0.as<float>(), nullptr, T));
+    TRYK(c, "sd_prep", 0, (double)T * 256 * 6, s, launch_sd_ln64_gelu(c->sd_u0.as<float>(), d.up_ln_g, d.up_ln_b, c->sd_u0_16.as<f16>(), T * 4, s));
+    TRY(img_gemm("sd_gemm", c->sd_u0_16.as<f16>(), 64, d.up1_w, 128, d.up1_b, nullptr, nullptr, 1, nullptr, c->sd_u1_16.as<f16>(), T * 4));
+    // hyper-network MLPs on the three mask tokens (tokens 1..3 of every tile): [B,3,256] -> [B,3,32]
+    for (int i = 0; i < 3; ++i) {
+        TRYK(c, "sd_token", 0, 0, s, lin(q + (size_t)(1 + i) * 256, 4 * 256, nullptr, 1, d.hy_w[i][0], d.hy_b[i][0], B, 256, 256, 2, hy0 + (size_t)i * 256, 3 * 256));
+        TRYK(c, "sd_token", 0, 0, s, lin(hy0 + (size_t)i * 256, 3 * 256, nullptr, 1, d.hy_w[i][1], d.hy_b[i][1], B, 256, 256, 2, hy1 + (size_t)i * 256, 3 * 256));
+        TRYK(c, "sd_token", 0, 0, s, lin(hy1 + (size_t)i * 256, 3 * 256, nullptr, 1, d.hy_w[i][2], d.hy_b[i][2], B, 32, 256, 0, hyper + (size_t)i * 32, 3 * 32));
+    }
+    TRYK(c, "sd_prep", 0, (double)T * 16 * 72, s, launch_sd_mask(c->sd_u1_16.as<f16>(), hyper, c->sd_low.as<float>(), B, S, s));
+    TRYK(c, "sd_prep", 0, (double)B * P * P * 16, s, launch_sd_upsample(c->sd_low.as<float>(), logits, scores, B, 4 * S, P, s));
+    (void)qn; (void)t3;
+    return 0;
+}
 
 static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B, float* logits, float* scores,
                         float* emb, hipStream_t s) {
@@ -503,6 +740,7 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         TRYK(c, "layernorm", 0, (double)T * 256 * 10, s, launch_layernorm(ln, s));
     }
     if (!logits && !scores) return 0;
+    if (w->cfg.use_sam_decoder) return sam_decode(c, w, B, emb, logits, scores, s);
     // map_decoder: 3 per-pixel GEMMs (ConvT k2 s2) + LN2d/GELU, then the fused 32->2 tail
     {
         GemmParams g;

@@ -123,4 +123,20 @@ struct TopoFusedParams {
 };
 int launch_topo_fused(const TopoFusedParams& p, hipStream_t s);
 
+// ---- SAM MaskDecoder branch (sam_decoder.hip; reference model.py:260-282, :426-443) ----------------------------------------
+struct SdLinearParams {                  // y[r,n] = act((x[r,:] + xadd[r % add_rows,:]) . W[n,:] + b[n]); f32, token side
+    const float* x = nullptr; int ldx = 0; const float* xadd = nullptr; int add_rows = 1;
+    const float* W = nullptr; const float* b = nullptr; int rows = 0, N = 0, K = 0, act = 0;
+    float* y = nullptr; int ldy = 0;
+};
+int launch_sd_add_channel(const float* emb, const float* vec, float* out_f32, f16* out_f16, size_t rows, hipStream_t s);
+int launch_sd_tok_linear(const SdLinearParams& p, hipStream_t s);
+int launch_sd_tok_ln(const float* x, const float* resid, const float* g, const float* b, float* y, int rows, hipStream_t s);
+int launch_sd_tok_selfattn(const float* q, const float* k, const float* v, float* out, int B, hipStream_t s);
+int launch_sd_t2i_attn(const float* q, const f16* K, const f16* V, float* out, int B, int HW, hipStream_t s);
+int launch_sd_i2t_attn(const f16* Q, const float* k, const float* v, f16* out, int B, int HW, hipStream_t s);
+int launch_sd_ln64_gelu(const float* x, const float* g, const float* b, f16* y, size_t rows, hipStream_t s);
+int launch_sd_mask(const f16* up, const float* hyper, float* low, int B, int S, hipStream_t s);
+int launch_sd_upsample(const float* low, float* logits, float* scores, int B, int L, int P, hipStream_t s);
+
 }  // namespace srh

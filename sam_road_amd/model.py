@@ -99,6 +99,69 @@ class _ImageEncoderParams(nn.Module):
                                   nn.Conv2d(256, 256, 3, padding=1, bias=False), _LayerNorm2dParams(256))
 
 
+class _SamAttnParams(nn.Module):
+    def __init__(self, dim, downsample):
+        super().__init__()
+        inner = dim // downsample
+        self.q_proj, self.k_proj, self.v_proj = nn.Linear(dim, inner), nn.Linear(dim, inner), nn.Linear(dim, inner)
+        self.out_proj = nn.Linear(inner, dim)
+
+
+class _SamTwoWayBlockParams(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.self_attn = _SamAttnParams(256, 1)
+        self.norm1 = nn.LayerNorm(256)
+        self.cross_attn_token_to_image = _SamAttnParams(256, 2)
+        self.norm2 = nn.LayerNorm(256)
+        self.mlp = nn.Module()
+        self.mlp.lin1, self.mlp.lin2 = nn.Linear(256, 2048), nn.Linear(2048, 256)
+        self.norm3 = nn.LayerNorm(256)
+        self.norm4 = nn.LayerNorm(256)
+        self.cross_attn_image_to_token = _SamAttnParams(256, 2)
+
+
+class _SamMlpParams(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+
+class _SamPromptEncoderParams(nn.Module):
+    """Parameter layout of the fork's PromptEncoder as constructed at model.py:263-268 (embed 256, mask_in_chans 16).  Only
+    no_mask_embed and the positional-encoding matrix are read by the no-prompt path the reference runs (model.py:427-429)."""
+
+    def __init__(self):
+        super().__init__()
+        self.pe_layer = nn.Module()
+        self.pe_layer.register_buffer("positional_encoding_gaussian_matrix", torch.randn((2, 128)))
+        self.point_embeddings = nn.ModuleList([nn.Embedding(1, 256) for _ in range(4)])
+        self.not_a_point_embed = nn.Embedding(1, 256)
+        self.mask_downscaling = nn.Sequential(nn.Conv2d(1, 4, 2, stride=2), _LayerNorm2dParams(4), nn.GELU(),
+                                              nn.Conv2d(4, 16, 2, stride=2), _LayerNorm2dParams(16), nn.GELU(),
+                                              nn.Conv2d(16, 256, 1))
+        self.no_mask_embed = nn.Embedding(1, 256)
+        for p in self.parameters():
+            p.requires_grad = False          # model.py:269-270
+
+
+class _SamMaskDecoderParams(nn.Module):
+    """Parameter layout of the fork's MaskDecoder + TwoWayTransformer as constructed at model.py:271-282."""
+
+    def __init__(self):
+        super().__init__()
+        self.transformer = nn.Module()
+        self.transformer.layers = nn.ModuleList([_SamTwoWayBlockParams() for _ in range(2)])
+        self.transformer.final_attn_token_to_image = _SamAttnParams(256, 2)
+        self.transformer.norm_final_attn = nn.LayerNorm(256)
+        self.iou_token = nn.Embedding(1, 256)
+        self.mask_tokens = nn.Embedding(3, 256)
+        self.output_upscaling = nn.Sequential(nn.ConvTranspose2d(256, 64, 2, stride=2), _LayerNorm2dParams(64), nn.GELU(),
+                                              nn.ConvTranspose2d(64, 32, 2, stride=2), nn.GELU())
+        self.output_hypernetworks_mlps = nn.ModuleList([_SamMlpParams([256, 256, 256, 32]) for _ in range(3)])
+        self.iou_prediction_head = _SamMlpParams([256, 256, 256, 3])
+
+
 class _TopoNetParams(nn.Module):
     def __init__(self, version):
         super().__init__()
@@ -118,9 +181,6 @@ class SAMRoad(nn.Module):
         assert config.SAM_VERSION in {"vit_b", "vit_l", "vit_h"}  # model.py:197
         if config.NO_SAM:
             raise NotImplementedError("NO_SAM ablation is not part of the release (reference model.py:232-242)")
-        if config.USE_SAM_DECODER:
-            raise NotImplementedError("USE_SAM_DECODER (SAM MaskDecoder branch, archived configs only) is not "
-                                      "built yet: SURVEY.md §8(f) rank 4")
         arch = dict(ARCH[config.SAM_VERSION])
         if config.ENCODER_DEPTH:  # test hook, not a reference key (absent => falsy => ignored)
             arch["depth"] = int(config.ENCODER_DEPTH)
@@ -131,11 +191,15 @@ class SAMRoad(nn.Module):
         self.register_buffer("pixel_std", torch.Tensor([58.395, 57.12, 57.375]).view(-1, 1, 1), False)
         lora_rank = int(config.LORA_RANK) if config.ENCODER_LORA else 0
         self.image_encoder = _ImageEncoderParams(config.PATCH_SIZE, lora_rank=lora_rank, **arch)
-        self.map_decoder = nn.Sequential(  # model.py:286-295 (indices 0,1,3,5,7 carry parameters)
-            nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2), _LayerNorm2dParams(128), nn.GELU(),
-            nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2), nn.GELU(),
-            nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2), nn.GELU(),
-            nn.ConvTranspose2d(32, 2, kernel_size=2, stride=2))
+        if config.USE_SAM_DECODER:  # model.py:260-282 (archived configs): SAM PromptEncoder (no prompts) + MaskDecoder
+            self.prompt_encoder = _SamPromptEncoderParams()
+            self.mask_decoder = _SamMaskDecoderParams()
+        else:
+            self.map_decoder = nn.Sequential(  # model.py:286-295 (indices 0,1,3,5,7 carry parameters)
+                nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2), _LayerNorm2dParams(128), nn.GELU(),
+                nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2), nn.GELU(),
+                nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2), nn.GELU(),
+                nn.ConvTranspose2d(32, 2, kernel_size=2, stride=2))
         # a YAML without TOPONET_VERSION (toponet_vith_256 / vitl_256 / vitb_256 / vitb_1024) yields an empty Config here; the
         # reference then takes every `!=` / `==` string comparison's "normal" branch (model.py:84,111-116)
         v = config.TOPONET_VERSION
@@ -224,6 +288,7 @@ class SAMRoad(nn.Module):
             cfg.global_attn_indexes[i] = g
         cfg.window_size = 14
         cfg.toponet_version = {"no_offset": 1, "no_transformer": 2}.get(self._topo_version, 0)
+        cfg.use_sam_decoder = 1 if self.config.USE_SAM_DECODER else 0
         names = [k for k in sd if ".linear_" not in k]
         arr = (_lib.NamedTensor * len(names))()
         keep = []

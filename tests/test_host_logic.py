@@ -236,8 +236,8 @@ def test_lora_keys_and_unsupported_configs():
     assert "image_encoder.blocks.3.attn.qkv.weight" in sd
     with pytest.raises(NotImplementedError):
         SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, NO_SAM=True))
-    with pytest.raises(NotImplementedError):
-        SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, USE_SAM_DECODER=True))
+    dec = SAMRoad(Config(SAM_VERSION="vit_b", PATCH_SIZE=256, USE_SAM_DECODER=True, SAM_CKPT_PATH="")).state_dict()
+    assert "mask_decoder.mask_tokens.weight" in dec and not any(k.startswith("map_decoder") for k in dec)
     with pytest.raises(AssertionError):
         SAMRoad(Config(SAM_VERSION="vit_x", PATCH_SIZE=256))
 
@@ -257,7 +257,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.srh_abi_version() == 1
+    assert lib.srh_abi_version() == 2
     # product package must not reference the oracle
     pkg = os.path.join(ROOT, "sam_road_amd")
     for fn in os.listdir(pkg):

@@ -1,12 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel trace + stats of bench.py, then two separate PMC passes
 # (FETCH_SIZE / WRITE_SIZE need different TCC slots).  Outputs under gpurun_out/<tag>_*; summarise with
-# tools/summarize_profile.py <tag> gpurun_out/<tag>_prof gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write
-TAG=${1:-r01b}
+# tools/summarize_profile.py <tag> gpurun_out/<tag>_prof gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write [workload]
+# usage: tools/profile_gpu.sh <tag> [encdec|full|vith256]   (outputs are tagged <tag> resp. <tag>_<workload>)
+TAG=${1:-r02}
+WORKLOAD=${2:-encdec}
+[ "$WORKLOAD" != encdec ] && TAG=${TAG}_${WORKLOAD}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline"
+BENCH="python $R/bench.py --workload $WORKLOAD --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-reference-gpu"
 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- $BENCH > $R/gpurun_out/${TAG}_prof.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pmc_fetch -o pmc -- $BENCH > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_pmc_write -o pmc -- $BENCH > $R/gpurun_out/${TAG}_pmc_write.log 2>&1

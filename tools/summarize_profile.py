@@ -27,9 +27,11 @@ def mean_by_kernel(path, counter):
 
 def main():
     tag, prof, fetch, write = sys.argv[1:5]
+    workload = sys.argv[5] if len(sys.argv) > 5 else "encdec"
+    sfx = "" if workload == "encdec" else "_" + workload          # bench.py picks the traffic summary of ITS workload by this suffix
     os.makedirs("profiles", exist_ok=True)
     for f in glob.glob(os.path.join(prof, "*kernel_stats.csv")):
-        shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+        shutil.copy(f, f"profiles/{tag}_kernel_stats{sfx}.csv")
     fe, wr = mean_by_kernel(fetch, "FETCH_SIZE"), mean_by_kernel(write, "WRITE_SIZE")
     out = {}
     for k in sorted(set(fe) | set(wr)):
@@ -44,7 +46,7 @@ def main():
     if tot_n:
         out["_gemm_all"] = {"launches_sampled": tot_n,
                             "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in gem) / tot_n}
-    json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+    json.dump(out, open(f"profiles/{tag}_hbm_traffic{sfx}.json", "w"), indent=1)
     for k, v in out.items():
         print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch (n={v['launches_sampled']})")
 

@@ -249,6 +249,11 @@ __device__ __forceinline__ void vt_write(char* vt, int kq, int dc, const uint4& 
 // ---------------------------------------------------------------------------------------------
 // Windowed attention: one workgroup per (image, head, window); the whole window's K and V^T
 // (196 keys incl. pad keys) are staged once, then each wave walks its 32-query tiles.
+// (Round 2 tried a PERSISTENT 8-wave form — one workgroup per CU, one wave per query tile, the next item's K / V / q prefetched
+// into registers during the key loop: correct but 48 % SLOWER, 85 vs 57 us per launch, profiles/r02_attn_window_p8.txt.  A
+// query tile's key loop costs ~6.5 us of VALU-issue-bound work, so an edge / corner window (2 / 1 tiles) parks 6 / 7 of the 8
+// waves for a whole tile time; with two independent 4-wave workgroups per CU the idle waves of one leave their SIMD's issue
+// slots to the other, and one workgroup's prologue overlaps the other's key loop.  History: git log.)
 // ---------------------------------------------------------------------------------------------
 constexpr int WIN_LDS_K = 7 * 4096, WIN_LDS_VT = 7 * 4096, WIN_LDS_RH = 4 * 32 * 17 * 4;
 constexpr int WIN_LDS = WIN_LDS_K + WIN_LDS_VT + WIN_LDS_RH;
@@ -414,169 +419,6 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
         store_query(st, p, tok, head, lane, valid);
         __builtin_amdgcn_wave_barrier();
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Windowed attention, PERSISTENT form: one 8-wave workgroup per CU walks (image, head, window) items.  Measured on the
-// one-workgroup-per-item kernel above (tools/attn_probe.py ablations): 56 % of its time is prologue / epilogue — global-load
-// latency of the 50 KB of K / V per item, the V^T transposition, and waves that idle because an item has 7 (full window),
-// 2 (edge) or 1 (corner) query tiles for 4 waves taking two tiles each in sequence.  Here
-//   * 8 waves: every query tile of an item (at most 7) has its own wave, so an item costs ONE tile's key loop, not two;
-//   * the NEXT item's K / V rows and query fragments are loaded into registers before the current item's key loop starts
-//     (order pinned with sched_barrier) and written to LDS after it: their HBM / L2 latency hides behind ~2.5 us of MFMA +
-//     softmax work instead of being exposed once per item;
-//   * the rel-pos table fragments (per layer, identical for every head and item) are loaded once per workgroup.
-// Item order = launch order of the non-persistent kernel (head fastest, then window), so a CU's consecutive items
-// blockIdx + k * gridDim cycle through full / edge / corner windows and the per-CU work is balanced.
-// ---------------------------------------------------------------------------------------------
-constexpr int WP8_LDS_RH = 8 * 32 * 17 * 4;
-constexpr int WP8_LDS_TAB = 2 * 32 * 128;                         // both rel-pos tables, 32 rows x 128 B each (rows >= 27 zero)
-constexpr int WP8_LDS = WIN_LDS_K + WIN_LDS_VT + WP8_LDS_RH + WP8_LDS_TAB;
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_window_p8_kernel(AttnParams p) {
-    constexpr int WIN = 14;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_lds = smem;
-    char* vt_lds = smem + WIN_LDS_K;
-    float* rh_lds = reinterpret_cast<float*>(smem + WIN_LDS_K + WIN_LDS_VT);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int S = p.S, nw = (S + WIN - 1) / WIN, D = p.heads * HD;
-    const int n_items = p.B * p.heads * nw * nw;
-    const int half = lane >> 5;
-    int item = blockIdx.x;
-    if (item >= n_items) return;
-
-    // rel-pos tables (per layer: identical for every head and item): staged once per workgroup into LDS in the K-tile layout
-    // (128-byte rows, 16-byte chunk XOR swizzle) so that their A fragments are conflict-free ds_read_b128 — holding the 8
-    // fragments in registers for the whole kernel cost 32 VGPRs and spilled
-    char* tab_lds = smem + WIN_LDS_K + WIN_LDS_VT + WP8_LDS_RH;
-    {
-        const int tb = tid >> 8, row = (tid >> 3) & 31, ch = tid & 7;
-        const f16* table = tb == 0 ? p.table_w : p.table_h;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < 2 * WIN - 1) v = *reinterpret_cast<const uint4*>(table + (size_t)row * HD + ch * 8);
-        *reinterpret_cast<uint4*>(tab_lds + tb * 4096 + row * 128 + swz8(row, ch) * 16) = v;
-    }
-    // staging roles.  K: thread (chunk s_c, local row s_i) of tiles t = 2 tt + s_tp; V: thread (d chunk s_dc, key quad s_kq) of tile t = wave
-    const int s_c = tid & 7, s_i = (tid >> 3) & 31, s_tp = tid >> 8;
-    const int s_dc = tid & 7, s_kq = (tid >> 3) & 7;
-    uint4 kreg[4], vreg[4];
-    f16x8 qpre[4];
-    int g_b, g_head, g_wy, g_wx, g_nrx, g_nreal;                     // geometry of the item whose data sits in kreg / vreg / qpre
-#define WP8_LOAD(it) { \
-    int u_ = (it); \
-    g_head = u_ % p.heads; u_ /= p.heads; \
-    const int widx_ = u_ % (nw * nw); g_b = u_ / (nw * nw); \
-    g_wy = widx_ / nw; g_wx = widx_ % nw; \
-    const int nry_ = min(WIN, S - g_wy * WIN); g_nrx = min(WIN, S - g_wx * WIN); g_nreal = nry_ * g_nrx; \
-    { int rr_, cc_; tile_rc<WIN>(s_i < 28 ? s_i : 0, rr_, cc_); \
-      _Pragma("unroll") for (int tt_ = 0; tt_ < 4; ++tt_) { \
-        const int t_ = min(2 * tt_ + s_tp, 6); \
-        const int y_ = g_wy * WIN + t_ * 2 + rr_, x_ = g_wx * WIN + cc_; \
-        const f16* src_ = (y_ < S && x_ < S) ? p.qkv + (((size_t)g_b * S + y_) * S + x_) * p.ld + D + g_head * HD : p.bias_qkv + D + g_head * HD; \
-        kreg[tt_] = *reinterpret_cast<const uint4*>(src_ + s_c * 8); } } \
-    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { \
-        const int i_ = s_kq * 4 + e_; int rr_, cc_; tile_rc<WIN>(i_ < 28 ? i_ : 0, rr_, cc_); \
-        const int y_ = g_wy * WIN + min(wave, 6) * 2 + rr_, x_ = g_wx * WIN + cc_; \
-        const f16* src_ = (y_ < S && x_ < S) ? p.qkv + (((size_t)g_b * S + y_) * S + x_) * p.ld + 2 * D + g_head * HD : p.bias_qkv + 2 * D + g_head * HD; \
-        vreg[e_] = *reinterpret_cast<const uint4*>(src_ + s_dc * 8); } \
-    { const int qi_ = min(wave * 32 + (lane & 31), g_nreal - 1); \
-      const size_t tokq_ = ((size_t)g_b * S + g_wy * WIN + qi_ / g_nrx) * S + g_wx * WIN + qi_ % g_nrx; \
-      const f16* q_ = p.qkv + tokq_ * p.ld + g_head * HD; \
-      _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) qpre[ks_] = *reinterpret_cast<const f16x8*>(q_ + (ks_ * 2 + half) * 8); } }
-
-    WP8_LOAD(item)
-    const float c_exp = p.scale * 1.4426950408889634f;
-    const float inv_scale = 1.0f / p.scale;
-    float* rh = rh_lds + wave * 32 * 17;
-    for (;;) {
-        // ---- the staged item goes to LDS (every wave has finished the previous item's key loop)
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int t = 2 * tt + s_tp;
-            if (t < 7) {
-                const uint4 v = s_i < 28 ? kreg[tt] : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(k_lds + t * 4096 + s_i * 128 + swz8(s_i, s_c) * 16) = v;
-            }
-        }
-        if (wave < 7) {
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            const int i0 = s_kq * 4;
-            vt_write(vt_lds + wave * 4096, s_kq, s_dc, i0 < 28 ? vreg[0] : z, i0 + 1 < 28 ? vreg[1] : z,
-                     i0 + 2 < 28 ? vreg[2] : z, i0 + 3 < 28 ? vreg[3] : z);
-        }
-        __syncthreads();
-        // ---- this item's query state; then the NEXT item's loads are put in flight before the key loop
-        QState st;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st.q[ks] = qpre[ks];
-        const int b = g_b, head = g_head, wy = g_wy, wx = g_wx, nrx = g_nrx, nreal = g_nreal;
-        const int ntq = (nreal + 31) / 32;
-        const int next = item + gridDim.x;
-        const bool has_next = next < n_items;
-        if (has_next) WP8_LOAD(next)
-        __builtin_amdgcn_sched_barrier(0);
-        if (wave < ntq) {
-            const int qi_raw = wave * 32 + (lane & 31);
-            const bool valid = qi_raw < nreal;
-            const int qi = valid ? qi_raw : nreal - 1;
-            const int ry = qi / nrx, rx = qi % nrx;
-            const size_t tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
-            st.m = -INFINITY;
-            st.l = 0.f;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
-            // fused rel-pos bias (see fused_relpos): w table -> st.relw, then h table -> rh
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int qc = pass == 0 ? rx : ry;
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int row = lane & 31;
-                    const f16x8 tf = *reinterpret_cast<const f16x8*>(tab_lds + pass * 4096 + row * 128 + swz8(row, ks * 2 + half) * 16);
-                    acc = mfma32(tf, st.q[ks], acc);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int jrow = mfma32_row(r, lane);
-                    const int k = qc - jrow + WIN - 1;
-                    if (k >= 0 && k < WIN && jrow < 2 * WIN - 1) rh[(lane & 31) * 17 + k] = acc[r] * inv_scale;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (pass == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int rr, cc;
-                        tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
-                        st.relw[r] = (cc < WIN) ? rh[(lane & 31) * 17 + cc] : 0.f;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            f16x8 kfA[4], kfB[4];
-            read_kfrag(kfA, k_lds, lane);
-#pragma unroll 1
-            for (int t = 0; t < 6; t += 2) {     // tiles 0..5 in pairs (next tile's K fragments prefetched), then tile 6
-                float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
-                read_kfrag(kfB, k_lds + (t + 1) * 4096, lane);
-                attn_tile<WIN>(st, kfA, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
-                rh0 = rh[(lane & 31) * 17 + 2 * t + 2]; rh1 = rh[(lane & 31) * 17 + 2 * t + 3];
-                read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
-                attn_tile<WIN>(st, kfB, vt_lds + (t + 1) * 4096, rh0, rh1, c_exp, lane);
-            }
-            attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rh[(lane & 31) * 17 + 12], rh[(lane & 31) * 17 + 13], c_exp, lane);
-            store_query(st, p, tok, head, lane, valid);
-        }
-        if (!has_next) break;
-        item = next;
-    }
-#undef WP8_LOAD
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -820,20 +662,7 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
             attr_set = true;
         }
         const int nw = (p.S + 13) / 14;
-        static const bool p8 = !(getenv("SRH_ATTN_WINDOW_P8") && atoi(getenv("SRH_ATTN_WINDOW_P8")) == 0);
-        const int n_items = p.B * nw * nw * p.heads;
-        if (p8) {       // persistent 8-wave form: one workgroup per CU
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0; hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
-                n_cu = prop.multiProcessorCount;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP8_LDS);
-            }
-            hipLaunchKernelGGL(attn_window_p8_kernel, dim3(n_items < n_cu ? n_items : n_cu), dim3(512), WP8_LDS, s, p);
-        } else {
-            hipLaunchKernelGGL(attn_window_kernel, dim3(n_items), dim3(256), WIN_LDS, s, p);
-        }
+        hipLaunchKernelGGL(attn_window_kernel, dim3(p.B * nw * nw * p.heads), dim3(256), WIN_LDS, s, p);
     } else {
         return -2;
     }

@@ -163,6 +163,13 @@ int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t 
 int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float threshold, int64_t* xy, uint8_t* scores,
                         int64_t capacity, int64_t* n);
 
+/* Votes of one TopoNet batch in the reference's visiting order (inferencer.py:206-221: tile, source point, neighbour slot):
+ * scores [nb, n_max, K] f32 host (NaN already replaced by -100), offsets [nb+1] rows of these tiles in ids / knn (the
+ * srh_pass2_fill layout).  Appends keys[*count] = ids[src] * n_points + ids[tgt] and the float64 score, advances *count;
+ * SRH_ERR_BAD_ARG if a valid pair's score is outside [0, 1] (the reference's assert, inferencer.py:219). */
+int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, int32_t K, const int64_t* offsets, const int64_t* ids,
+                    const int32_t* knn, int64_t n_points, int64_t* keys, double* votes, int64_t capacity, int64_t* count);
+
 /* Directed edge votes of pass 2 (reference inferencer.py:209-221: dict of score sums / counts keyed by (src, tgt), filled in
  * tile / point / slot order).  keys[i] = src * n_points + tgt, scores[i] in that visiting order.  Writes the unique keys in
  * ascending order with their float64 sums — accumulated in the reference's order, hence bit-identical to its loop — and

@@ -67,8 +67,9 @@ extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int6
 // ---------------------------------------------------------------------------------------------------------------
 // Pass-2 query builder for ALL tiles of a scene in one call (reference inferencer.py:148-176, executed per tile from
 // Python there: rtree box query + scipy KDTree.query(k = K+1, distance_upper_bound = R)).  For every tile: the points
-// inside the CLOSED box [x0,x1] x [y0,y1] in ascending point index (= the reference's order after its rtree query +
-// sort), and for each of them its K nearest OTHER points of the same tile with distance STRICTLY below R (scipy's
+// inside the CLOSED box [x0,x1] x [y0,y1] in ascending point index (the order chosen HERE: the reference takes whatever
+// order rtree.intersection yields and does not sort; its edge set does not depend on that order — pinned under three
+// different orders by tests/test_refrun_golden.py — only the order of its edge list does), and for each of them its K nearest OTHER points of the same tile with distance STRICTLY below R (scipy's
 // distance_upper_bound is exclusive), ascending by (distance, tile-local index); missing neighbours are -1.
 // The neighbour SET is what the reference computes whenever it is unique.  It is not unique when the (K+1)-th and the
 // (K+2)-th candidate are equidistant (scipy keeps whichever its heap met first) or when another point coincides with the
@@ -216,6 +217,41 @@ extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* score
         out_counts[u] += 1.0;
     }
     *n_unique = u + 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Directed edge votes of ONE TopoNet batch (reference inferencer.py:206-221: the triple Python loop over tiles, source
+// points and neighbour slots that fills the (src, tgt)-keyed dicts).  scores [nb, n_max, K] f32 = infer_toponet output
+// (NaN already mapped to -100 as inferencer.py:206 does) of nb consecutive tiles whose query rows are offsets[0..nb] into
+// ids / knn (srh_pass2_fill layout, knn = tile-local target or -1).  Appends, in the reference's visiting order,
+// keys[*count] = ids[src] * n_points + ids[tgt] and the score as float64; *count is advanced.  Returns SRH_ERR_BAD_ARG if a
+// valid pair's score is outside [0, 1] (the reference asserts that, inferencer.py:219).
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, int32_t K, const int64_t* offsets,
+                               const int64_t* ids, const int32_t* knn, int64_t n_points, int64_t* keys, double* votes,
+                               int64_t capacity, int64_t* count) {
+    if (!scores || !offsets || !ids || !knn || !keys || !votes || !count || nb < 0 || K <= 0) return SRH_ERR_BAD_ARG;
+    int64_t c = *count;
+    for (int32_t b = 0; b < nb; ++b) {
+        const int64_t a = offsets[b], n = offsets[b + 1] - a;
+        if (n > n_max) return SRH_ERR_BAD_ARG;
+        for (int64_t si = 0; si < n; ++si) {
+            const int32_t* row = knn + (a + si) * K;
+            const float* sc = scores + ((int64_t)b * n_max + si) * K;
+            const int64_t src = ids[a + si] * n_points;
+            for (int32_t pi = 0; pi < K; ++pi) {
+                if (row[pi] < 0) continue;
+                const float v = sc[pi];
+                if (!(v >= 0.0f && v <= 1.0f)) return SRH_ERR_BAD_ARG;
+                if (c >= capacity) return SRH_ERR_BAD_ARG;
+                keys[c] = src + ids[a + row[pi]];
+                votes[c] = (double)v;
+                ++c;
+            }
+        }
+    }
+    *count = c;
     return 0;
 }
 

@@ -40,20 +40,40 @@ def build_patch_queries(graph_points, x0, y0, x1, y1, config):
     return ids, pts, np.stack([src, tgt], -1), valid
 
 
-def build_all_patch_queries(graph_points, infos, lo, hi, config):
+class _FlatQueries:
+    """Pass-2 queries of tiles [lo, hi) as flat arrays (the library's layout): offsets [n_tiles+1] rows per tile, ids [total]
+    global point index of every row, local [total,2] tile-local (x, y), knn [total,K] int32 tile-local target or -1."""
+
+    def __init__(self, offsets, ids, local, knn):
+        self.offsets, self.ids, self.local, self.knn = offsets, ids, local, knn
+        self.n_tiles = offsets.shape[0] - 1
+
+    def tile(self, t):
+        """(ids, points, pairs[n,K,2], valid[n,K]) of tile t in the reference's per-tile form (inferencer.py:148-176)."""
+        a, b = int(self.offsets[t]), int(self.offsets[t + 1])
+        knn = self.knn[a:b]
+        valid = knn >= 0
+        src = np.arange(b - a, dtype=np.int64)[:, None]
+        pairs = np.stack([np.broadcast_to(src, knn.shape), np.where(valid, knn, src)], axis=-1)
+        return self.ids[a:b], self.local[a:b], pairs, valid
+
+
+def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     """build_patch_queries for tiles [lo, hi) in ONE call into the library's host code (srh_pass2_count / srh_pass2_fill,
-    csrc/host_geom.hip: closed-box filter + exact integer kNN per tile, worker threads).  Tiles whose scipy result is not
-    determined by distances alone (tie at the k-th neighbour, coincident points) are recomputed with the reference's own
-    scipy call, so the neighbour SETS always equal the reference's; the order inside a group of equidistant neighbours
-    is scipy-internal and nothing downstream depends on it."""
+    csrc/host_geom.hip: closed-box filter + exact integer kNN per tile, worker threads).  Source points whose scipy result is
+    not determined by distances alone (tie at the k-th neighbour, coincident points) are recomputed with the reference's own
+    scipy call on a kd-tree of their tile's points (ids ascending), so the neighbour SETS equal those of the reference's call;
+    the order inside a group of equidistant neighbours is scipy-internal.  Returns a list of per-tile tuples, or the flat form."""
     import ctypes as C
     import os
     from . import _lib
     k, r = int(config.MAX_NEIGHBOR_QUERIES), config.NEIGHBOR_RADIUS
     n_tiles = hi - lo
     if n_tiles <= 0:
-        return []
+        return None if flat else []
     if float(r) != int(r) or not np.issubdtype(graph_points.dtype, np.integer):
+        if flat:
+            return None
         return [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
     import time
     prof = os.environ.get("SRH_PROFILE_HOST") == "1"
@@ -80,13 +100,9 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config):
         raise _lib.SrhError("srh_pass2_fill failed")
     lap("count + fill (library)")
     tile_of = np.repeat(np.arange(n_tiles), counts)
-    src_local = np.arange(total, dtype=np.int64) - offsets[:-1][tile_of]
-    valid = knn >= 0
-    pairs = np.stack([np.broadcast_to(src_local[:, None], (total, k)), np.where(valid, knn, src_local[:, None])], axis=-1)
     local = pts[ids] - boxes[tile_of, :2].astype(np.int64)
-    cut = offsets[1:-1]
-    # ambiguous source points: the reference's own scipy query, on a kd-tree of their tile's points (rows overwritten in place)
     lap("numpy post")
+    # ambiguous source points: the reference's own scipy query, on a kd-tree of their tile's points (rows overwritten in place)
     amb_rows = np.nonzero(amb)[0]
     if amb_rows.size:
         # scipy.spatial.KDTree(pts) IS cKDTree(pts, leafsize=10, compact_nodes=True, balanced_tree=True) behind a Python
@@ -99,13 +115,12 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config):
             tree = scipy.spatial.cKDTree(local[a:b_], leafsize=10)
             _, nn = tree.query(local[rows], k=k + 1, distance_upper_bound=r)
             nn = nn[:, 1:]
-            ok = nn < (b_ - a)
-            valid[rows] = ok
-            pairs[rows, :, 1] = np.where(ok, nn, (rows - a)[:, None])
+            knn[rows] = np.where(nn < (b_ - a), nn, -1)
     lap("tied re-queries")
-    out = list(zip(np.split(ids, cut), np.split(local, cut), np.split(pairs, cut), np.split(valid, cut)))
-    lap("split")
-    return out
+    fq = _FlatQueries(offsets, ids, local, knn)
+    if flat:
+        return fq
+    return [fq.tile(t) for t in range(n_tiles)]
 
 
 def _collate(xs):
@@ -119,10 +134,12 @@ def _collate(xs):
 
 def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
     """Pass 2 over tiles [lo, hi) whose embeddings are emb[0 : hi-lo] (inferencer.py:135-221): returns the
-    unique directed edge keys (src * n_points + tgt) with their score sums and counts.  The sums are accumulated in
-    float64 in the reference's order (tile, point, neighbour slot), so they are bit-identical to its dict loop."""
+    unique directed edge keys (src * n_points + tgt) with their score sums, counts and first-vote positions.  The sums are
+    accumulated in float64 in the reference's order (tile, point, neighbour slot), so they are bit-identical to its dict loop."""
+    import ctypes as C
     import os
     import time
+    from . import _lib
     prof = os.environ.get("SRH_PROFILE_HOST") == "1"      # tuning aid: print the wall time of each section
     t_sec = [time.perf_counter()]
     def lap(name):
@@ -131,49 +148,91 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
             print(f"[edge_votes] {name}: {(t_sec[-1] - t_sec[-2]) * 1e3:.1f} ms", flush=True)
     bs = int(config.INFER_BATCH_SIZE)
     n_pts = graph_points.shape[0]
-    all_q = build_all_patch_queries(graph_points, infos, lo, hi, config)
+    K = int(config.MAX_NEIGHBOR_QUERIES)
+    empty = (np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0, np.int64))
+    fq = build_all_patch_queries(graph_points, infos, lo, hi, config, flat=True)
     lap("build_all_patch_queries")
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if fq is None:
+        # non-integer coordinates / radius: the reference's per-tile scipy path, votes gathered in numpy
+        if hi - lo <= 0:
+            return empty
+        all_q = [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
     # launch every batch before fetching any scores.  Indices travel as int32 and the integer pixel coordinates as float32
     # (exact; srh_toponet accepts both, model.py:47's division promotes anyway).
     launched = []
     for off in range(lo, hi, bs):
         end = min(off + bs, hi)
-        qs = all_q[off - lo:end - lo]
-        if max(q[1].shape[0] for q in qs) == 0:
-            continue
-        pts = _collate([q[1].astype(np.float32) for q in qs])
-        pairs = _collate([q[2].astype(np.int32) for q in qs])
-        valid = _collate([q[3] for q in qs])
+        if fq is not None:
+            a, b = int(fq.offsets[off - lo]), int(fq.offsets[end - lo])
+            cnt = np.diff(fq.offsets[off - lo:end - lo + 1])
+            n_max = int(cnt.max())
+            if n_max == 0:
+                continue
+            nb = end - off
+            # padded collate (inferencer.py:179-185) by one scatter: row r of tile t -> [t, r]
+            t_of = np.repeat(np.arange(nb), cnt)
+            r_of = np.arange(b - a) - np.repeat(fq.offsets[off - lo:end - lo] - a, cnt)
+            pts = np.zeros((nb, n_max, 2), np.float32)
+            pts[t_of, r_of] = fq.local[a:b]
+            knn = fq.knn[a:b]
+            valid = np.zeros((nb, n_max, K), bool)
+            valid[t_of, r_of] = knn >= 0
+            pairs = np.zeros((nb, n_max, K, 2), np.int32)
+            pairs[t_of, r_of, :, 0] = r_of[:, None]
+            pairs[t_of, r_of, :, 1] = np.where(knn >= 0, knn, r_of[:, None])
+            qs = None
+        else:
+            qs = all_q[off - lo:end - lo]
+            if max(q[1].shape[0] for q in qs) == 0:
+                continue
+            pts = _collate([q[1].astype(np.float32) for q in qs])
+            pairs = _collate([q[2].astype(np.int32) for q in qs])
+            valid = _collate([q[3] for q in qs])
         scores = net.infer_toponet(emb[off - lo:end - lo], torch.as_tensor(pts).to(device, non_blocking=True),
                                    torch.as_tensor(pairs).to(device, non_blocking=True),
                                    torch.as_tensor(valid).to(device, non_blocking=True))
-        launched.append((qs, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
+        launched.append((off, end, qs, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
     lap("collate + H2D + launch")
-    keys_l, score_l = [], []
-    for qs, scores_dev in launched:
-        scores = scores_dev.cpu().numpy()
-        for b, (ids, _, prs, vld) in enumerate(qs):
-            n = len(ids)
-            if n == 0:
-                continue
-            sc = scores[b, :n][vld]
-            assert ((sc >= 0.0) & (sc <= 1.0)).all()
-            keys_l.append(ids[prs[:, :, 0]][vld].astype(np.int64) * n_pts + ids[prs[:, :, 1]][vld].astype(np.int64))
-            score_l.append(sc.astype(np.float64))
-    if not keys_l:
-        return np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0, np.int64)
+    if not launched:
+        return empty
+    if fq is not None:
+        cap = int((fq.knn >= 0).sum())
+        k = np.empty(cap, np.int64)
+        s = np.empty(cap, np.float64)
+        cnt_c = C.c_int64(0)
+        for off, end, _, scores_dev in launched:
+            sc = np.ascontiguousarray(scores_dev.cpu().numpy(), dtype=np.float32)
+            rc = lib.srh_pass2_votes(vp(sc), end - off, sc.shape[1], K, vp(fq.offsets[off - lo:]), vp(fq.ids), vp(fq.knn), n_pts,
+                                     vp(k), vp(s), cap, C.byref(cnt_c))
+            if rc != 0:
+                raise AssertionError("edge score outside [0, 1] (reference inferencer.py:219) or inconsistent query arrays")
+        k, s = k[:cnt_c.value], s[:cnt_c.value]
+    else:
+        keys_l, score_l = [], []
+        for off, end, qs, scores_dev in launched:
+            scores = scores_dev.cpu().numpy()
+            for b, (ids, _, prs, vld) in enumerate(qs):
+                n = len(ids)
+                if n == 0:
+                    continue
+                sc = scores[b, :n][vld]
+                assert ((sc >= 0.0) & (sc <= 1.0)).all()
+                keys_l.append(ids[prs[:, :, 0]][vld].astype(np.int64) * n_pts + ids[prs[:, :, 1]][vld].astype(np.int64))
+                score_l.append(sc.astype(np.float64))
+        if not keys_l:
+            return empty
+        k = np.ascontiguousarray(np.concatenate(keys_l), dtype=np.int64)
+        s = np.ascontiguousarray(np.concatenate(score_l), dtype=np.float64)
     lap("score fetch + keys")
-    k = np.ascontiguousarray(np.concatenate(keys_l), dtype=np.int64)
-    s = np.ascontiguousarray(np.concatenate(score_l), dtype=np.float64)
+    if k.shape[0] == 0:
+        return empty
     # the reference's dict accumulation (float64 sums in visiting order) as a stable radix sort by key + one sequential pass
     # in the library's host code (np.unique + np.bincount did the same in 11 ms per CityScale scene, this takes ~3)
-    import ctypes as C
-    from . import _lib
     uk, sums, cnts, first = np.empty_like(k), np.empty_like(s), np.empty_like(s), np.empty_like(k)
     nu = C.c_int64(0)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    if _lib.load().srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), vp(first),
-                                            C.byref(nu)) != 0:
+    if lib.srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), vp(first), C.byref(nu)) != 0:
         raise _lib.SrhError("srh_edge_vote_accumulate failed")
     lap("accumulate")
     return uk[:nu.value], sums[:nu.value], cnts[:nu.value], first[:nu.value]
@@ -208,18 +267,32 @@ def infer_one_img(net, img, config, device=None):
     rank = torch.distributed.get_rank() if D.is_distributed() else 0
     lo, hi = shard_tiles(len(infos), world, rank)
 
+    import os
+    import time
+    prof = os.environ.get("SRH_PROFILE_HOST") == "1"      # tuning aid: wall time of each stage (synchronises the device)
+    t_sec = [time.perf_counter()]
+    def lap(name):
+        if prof:
+            torch.cuda.synchronize(device)
+            t_sec.append(time.perf_counter())
+            print(f"[infer_one_img] {name}: {(t_sec[-1] - t_sec[-2]) * 1e3:.1f} ms", flush=True)
+
     # ---- pass 1 (GPU): crop -> encoder -> decoder -> fused canvases; embeddings stay resident
     scene = torch.as_tensor(np.ascontiguousarray(img), dtype=torch.uint8).to(device)
     xy_dev = torch.as_tensor(all_xy).to(device)
+    lap("scene upload")
     assert all_xy.min() >= 0 and all_xy.max() + int(config.PATCH_SIZE) <= image_size
     kp_c, road_c, emb = net.scene_pass1(scene, xy_dev[lo:hi], bs)      # an empty shard (world > n_tiles) returns zero canvases
+    lap("pass 1 (GPU)")
     D.reduce_canvases(kp_c, road_c, dst=0)
     graph_points = None
     kp_mask = road_mask = None
     if rank == 0:
         kp_u8, road_u8 = net.scene_normalise(kp_c, road_c, xy_dev)
         kp_mask, road_mask = kp_u8.cpu().numpy(), road_u8.cpu().numpy()
+        lap("normalise + mask D2H")
         graph_points = extract_graph_points(kp_mask, road_mask, config)
+        lap("extract_graph_points")
     graph_points = D.broadcast_points(graph_points, src=0, device=device if world > 1 else None)
     if graph_points.shape[0] == 0:
         if rank != 0:
@@ -229,12 +302,14 @@ def infer_one_img(net, img, config, device=None):
     # ---- pass 2: per-tile queries (host) -> sampler + TopoNet (GPU) -> directed edge votes
     n_pts = graph_points.shape[0]
     uk, sums, cnts, first = edge_votes(net, emb, graph_points, infos, lo, hi, config, device)
+    lap("edge_votes")
     uk, sums, cnts, first = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None,
                                                 first=first)
     if rank != 0:
         return None
     pred_edges = votes_to_edges(uk, sums, cnts, first, n_pts, config.TOPO_THRESHOLD)
     pred_nodes = graph_points[:, ::-1]  # (row, col)
+    lap("threshold + edge list")
     return pred_nodes, pred_edges, kp_mask, road_mask
 
 

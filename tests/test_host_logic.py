@@ -283,3 +283,44 @@ def test_config_missing_keys_copy_pickle_and_toponet_default():
     assert copy.deepcopy(net).state_dict().keys() == net.state_dict().keys()
     net2 = SAMRoad(Config(dict(cfg, TOPONET_VERSION="no_transformer")))
     assert net2._topo_version == "no_transformer" and not hasattr(net2.topo_net, "transformer_encoder")
+
+
+def test_pass2_votes_match_reference_triple_loop():
+    """srh_pass2_votes == the reference's triple loop over (tile, source point, neighbour slot) (inferencer.py:209-221): same
+    keys and scores in the same visiting order; a score outside [0, 1] is refused (the reference asserts)."""
+    import ctypes as C
+    from sam_road_amd.inferencer import build_all_patch_queries
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(5)
+    pts = np.unique(rng.integers(0, 300, size=(400, 2)), axis=0).astype(np.int64)
+    cfg = Config(NEIGHBOR_RADIUS=40, MAX_NEIGHBOR_QUERIES=16)
+    infos = get_patch_info_one_img(0, 320, 0, 128, 4)
+    fq = build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+    K, n_pts = 16, pts.shape[0]
+    nb, t0 = 5, 3                                     # a "batch" of tiles 3..7
+    cnt = np.diff(fq.offsets[t0:t0 + nb + 1])
+    n_max = int(cnt.max()) + 2                        # padded rows beyond a tile's points are never read
+    scores = rng.random((nb, n_max, K)).astype(np.float32)
+    cap = int((fq.knn >= 0).sum())
+    keys, votes = np.empty(cap, np.int64), np.empty(cap, np.float64)
+    c = C.c_int64(0)
+    assert lib.srh_pass2_votes(vp(scores), nb, n_max, K, vp(fq.offsets[t0:]), vp(fq.ids), vp(fq.knn), n_pts, vp(keys), vp(votes),
+                               cap, C.byref(c)) == 0
+    want_k, want_s = [], []
+    for b in range(nb):
+        ids, _, pairs, valid = fq.tile(t0 + b)
+        for si in range(len(ids)):
+            for pi in range(K):
+                if valid[si, pi]:
+                    want_k.append(int(ids[pairs[si, pi, 0]]) * n_pts + int(ids[pairs[si, pi, 1]]))
+                    want_s.append(float(scores[b, si, pi]))
+    assert c.value == len(want_k) > 100
+    np.testing.assert_array_equal(keys[:c.value], want_k)
+    np.testing.assert_array_equal(votes[:c.value], want_s)
+    scores[1, 0, 0] = 1.5 if fq.knn[fq.offsets[t0 + 1], 0] >= 0 else scores[1, 0, 0]
+    scores[0, 0, 0] = np.nan
+    c = C.c_int64(0)
+    if fq.knn[fq.offsets[t0], 0] >= 0:
+        assert lib.srh_pass2_votes(vp(scores), nb, n_max, K, vp(fq.offsets[t0:]), vp(fq.ids), vp(fq.knn), n_pts, vp(keys), vp(votes),
+                                   cap, C.byref(c)) != 0

@@ -160,40 +160,50 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
             return empty
         all_q = [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
     # launch every batch before fetching any scores.  Indices travel as int32 and the integer pixel coordinates as float32
-    # (exact; srh_toponet accepts both, model.py:47's division promotes anyway).
+    # (exact; srh_toponet accepts both, model.py:47's division promotes anyway).  All batches' padded arrays are built into
+    # ONE host buffer per kind and uploaded with one blocking copy each: per-batch non_blocking uploads of pageable numpy
+    # memory went through torch's pinned-staging allocator and stalled 30-40 ms in some scenes (profiles/r02_scene_stages.txt).
     launched = []
-    for off in range(lo, hi, bs):
-        end = min(off + bs, hi)
-        if fq is not None:
-            a, b = int(fq.offsets[off - lo]), int(fq.offsets[end - lo])
+    if fq is not None:
+        plan, rows_total = [], 0
+        for off in range(lo, hi, bs):
+            end = min(off + bs, hi)
             cnt = np.diff(fq.offsets[off - lo:end - lo + 1])
             n_max = int(cnt.max())
-            if n_max == 0:
-                continue
-            nb = end - off
-            # padded collate (inferencer.py:179-185) by one scatter: row r of tile t -> [t, r]
-            t_of = np.repeat(np.arange(nb), cnt)
+            if n_max:
+                plan.append((off, end, cnt, n_max, rows_total))
+                rows_total += (end - off) * n_max
+        pts_h = np.zeros((max(rows_total, 1), 2), np.float32)
+        pairs_h = np.zeros((max(rows_total, 1), K, 2), np.int32)
+        valid_h = np.zeros((max(rows_total, 1), K), np.uint8)
+        for off, end, cnt, n_max, base in plan:
+            a, b = int(fq.offsets[off - lo]), int(fq.offsets[end - lo])
+            # padded collate (inferencer.py:179-185) by one scatter: row r of tile t -> base + t * n_max + r
             r_of = np.arange(b - a) - np.repeat(fq.offsets[off - lo:end - lo] - a, cnt)
-            pts = np.zeros((nb, n_max, 2), np.float32)
-            pts[t_of, r_of] = fq.local[a:b]
+            dst = base + np.repeat(np.arange(end - off), cnt) * n_max + r_of
             knn = fq.knn[a:b]
-            valid = np.zeros((nb, n_max, K), bool)
-            valid[t_of, r_of] = knn >= 0
-            pairs = np.zeros((nb, n_max, K, 2), np.int32)
-            pairs[t_of, r_of, :, 0] = r_of[:, None]
-            pairs[t_of, r_of, :, 1] = np.where(knn >= 0, knn, r_of[:, None])
-            qs = None
-        else:
+            pts_h[dst] = fq.local[a:b]
+            valid_h[dst] = knn >= 0
+            pairs_h[dst, :, 0] = r_of[:, None]
+            pairs_h[dst, :, 1] = np.where(knn >= 0, knn, r_of[:, None])
+        pts_d, pairs_d, valid_d = (torch.from_numpy(x).to(device) for x in (pts_h, pairs_h, valid_h))
+        for off, end, cnt, n_max, base in plan:
+            nb, sl = end - off, slice(base, base + (end - off) * n_max)
+            scores = net.infer_toponet(emb[off - lo:end - lo], pts_d[sl].view(nb, n_max, 2), pairs_d[sl].view(nb, n_max, K, 2),
+                                       valid_d[sl].view(nb, n_max, K))
+            launched.append((off, end, None, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
+    else:
+        for off in range(lo, hi, bs):
+            end = min(off + bs, hi)
             qs = all_q[off - lo:end - lo]
             if max(q[1].shape[0] for q in qs) == 0:
                 continue
             pts = _collate([q[1].astype(np.float32) for q in qs])
             pairs = _collate([q[2].astype(np.int32) for q in qs])
             valid = _collate([q[3] for q in qs])
-        scores = net.infer_toponet(emb[off - lo:end - lo], torch.as_tensor(pts).to(device, non_blocking=True),
-                                   torch.as_tensor(pairs).to(device, non_blocking=True),
-                                   torch.as_tensor(valid).to(device, non_blocking=True))
-        launched.append((off, end, qs, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
+            scores = net.infer_toponet(emb[off - lo:end - lo], torch.as_tensor(pts).to(device), torch.as_tensor(pairs).to(device),
+                                       torch.as_tensor(valid).to(device))
+            launched.append((off, end, qs, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
     lap("collate + H2D + launch")
     if not launched:
         return empty

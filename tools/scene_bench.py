@@ -6,6 +6,8 @@ whole infer_one_img (pass 1 + host NMS + pass-2 queries + TopoNet + edge vote). 
 lowered so that the random network yields sparse masks (a few thousand graph points, as a trained one does).
 
     python tools/scene_bench.py [--bias -2.2] [--wscale 16] [--batch 64] [--iters 3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/scene_bench.py    # N GPUs:
+        tiles sharded over the ranks (RCCL: weight broadcast, canvas reduce, point broadcast, vote gather); rank 0 prints
 """
 import argparse
 import json
@@ -28,7 +30,15 @@ def main():
     args = ap.parse_args()
     from sam_road_amd import Config, SAMRoad
     from sam_road_amd.inferencer import infer_one_img
-    from sam_road_amd.tiling import get_patch_info_one_img
+    from sam_road_amd.tiling import get_patch_info_one_img, shard_tiles
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
     cfg = Config(SAM_VERSION="vit_b", PATCH_SIZE=512, TOPONET_VERSION="normal", SAM_CKPT_PATH="", DATASET="cityscale",
                  INFER_BATCH_SIZE=args.batch, SAMPLE_MARGIN=64, INFER_PATCHES_PER_EDGE=16, ITSC_THRESHOLD=0.248,
                  ROAD_THRESHOLD=0.364, TOPO_THRESHOLD=0.499, ITSC_NMS_RADIUS=8, ROAD_NMS_RADIUS=16, NEIGHBOR_RADIUS=64,
@@ -43,18 +53,22 @@ def main():
             sd[k] = 0.02 * torch.randn(v.shape, generator=g)
     sd["map_decoder.7.weight"] = args.wscale * torch.randn(sd["map_decoder.7.weight"].shape, generator=g)
     sd["map_decoder.7.bias"] = torch.full_like(sd["map_decoder.7.bias"], args.bias)
+    if world > 1:
+        from sam_road_amd.distributed import broadcast_state_dict
+        sd = broadcast_state_dict(sd, src=0, device=dev)      # one flat RCCL broadcast over xGMI (every rank seeded identically anyway)
     net.load_state_dict(sd, strict=True)
-    net.eval().to("cuda")
+    net.eval().to(dev)
     rng = np.random.default_rng(0)
     coarse = rng.integers(0, 256, size=(2048 // 8, 2048 // 8, 3)).astype(np.float32)
     img = np.kron(coarse, np.ones((8, 8, 1), np.float32)).astype(np.uint8)
 
     infos = get_patch_info_one_img(0, 2048, cfg.SAMPLE_MARGIN, cfg.PATCH_SIZE, cfg.INFER_PATCHES_PER_EDGE)
-    xy = torch.as_tensor(np.array([[p[1][0], p[1][1]] for p in infos], dtype=np.int32)).cuda()
-    scene = torch.as_tensor(img).cuda()
+    xy = torch.as_tensor(np.array([[p[1][0], p[1][1]] for p in infos], dtype=np.int32)).to(dev)
+    scene = torch.as_tensor(img).to(dev)
+    lo, hi = shard_tiles(len(infos), world, rank)
 
-    def pass1():
-        kp, road, emb = net.scene_pass1(scene, xy, args.batch)
+    def pass1():              # this rank's share of the tiles (no collective: tile throughput)
+        kp, road, emb = net.scene_pass1(scene, xy[lo:hi], args.batch)
         kpu, ru = net.scene_normalise(kp, road, xy)
         return kpu.cpu(), ru.cpu()
 
@@ -84,14 +98,24 @@ def main():
         res = infer_one_img(net, img, cfg)
     torch.cuda.synchronize()
     full = (time.perf_counter() - t0) / args.iters
+    if world > 1:
+        t = torch.tensor([p1, full], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        p1, full = t.tolist()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
     nodes, edges, kp, road = res
-    print(json.dumps({"scene": "synthetic 2048x2048 u8, 256 tiles of 512^2 (16x16, margin 64)", "n_gpus": 1,
+    print(json.dumps({"scene": "synthetic 2048x2048 u8, 256 tiles of 512^2 (16x16, margin 64)", "n_gpus": world,
                       "infer_batch_size": args.batch, "ms_per_scene_pass1": round(1e3 * p1, 2),
                       "tiles_per_s_pass1": round(256 / p1, 1), "ms_per_scene_full": round(1e3 * full, 2),
                       "ms_extract_graph_points": round(1e3 * acc["extract_graph_points"] / args.iters, 2),
                       "ms_edge_votes": round(1e3 * acc["edge_votes"] / args.iters, 2), "graph_points": int(nodes.shape[0]), "edges": int(edges.shape[0]),
                       "kp_mask_frac": float((kp > cfg.ITSC_THRESHOLD * 255).mean()),
                       "road_mask_frac": float((road > cfg.ROAD_THRESHOLD * 255).mean())}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

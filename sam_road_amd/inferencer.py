@@ -260,6 +260,21 @@ def votes_to_edges(uk, sums, cnts, first, n_pts, threshold):
 
 
 def infer_one_img(net, img, config, device=None):
+    """reference inferencer.py:61-234: (pred_nodes (row, col), pred_edges, keypoint_mask u8, road_mask u8) of one scene.  The cyclic
+    garbage collector is paused for the duration of the call: a generation-2 sweep over the interpreter's objects landed inside
+    roughly one scene in four and cost ~20 ms of a ~120 ms scene (profiles/r02_scene_stages.txt); reference counting still frees
+    every array as it goes."""
+    import gc
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _infer_one_img(net, img, config, device)
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _infer_one_img(net, img, config, device=None):
     device = torch.device(device) if device is not None else next(net.parameters()).device
     img = np.asarray(img)
     # the reference uses img.shape[0] for both axes (inferencer.py:63,67) and casts whatever it gets to f32; a non-square or

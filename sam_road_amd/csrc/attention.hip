@@ -627,9 +627,13 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
 }
 
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
-    static const int env_abl = getenv("SRH_ATTN_ABL") ? atoi(getenv("SRH_ATTN_ABL")) : 0;
     AttnParams p = p_in;
+#ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): ablation switches change the RESULT
+    static const int env_abl = getenv("SRH_ATTN_ABL") ? atoi(getenv("SRH_ATTN_ABL")) : 0;
     if (!p.ablate) p.ablate = env_abl;
+#else
+    p.ablate = 0;
+#endif
     const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32)));
     static const bool use_hdx = !(getenv("SRH_ATTN_HDX") && atoi(getenv("SRH_ATTN_HDX")) == 0);
     if (!mfma_path && use_hdx && attention_hdx_supported(p)) return launch_attention_hdx(p, s);

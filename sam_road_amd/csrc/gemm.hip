@@ -522,9 +522,13 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.N % 128 != 0 || p.K % BK != 0) return -2;
     if (p.conv_S > 0 && (p.conv_C % BK != 0)) return -2;
     if (p.conv_S > 0) return launch_cfg<1, 2, 2, 2, 2>(p, stream);
-    static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;   // tuning aid
+#ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): kernel / ablation selection by number
+    static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
     const int variant = p.variant ? p.variant : env_variant;
-    if (variant >= 50 && variant <= 59) return launch_gemm_q192(p, stream, variant - 50);
+    if (variant >= 50 && variant <= 60) return launch_gemm_q192(p, stream, variant - 50);
+#else
+    const int variant = 0;
+#endif
     // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
     static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
     if (variant == 0 && use_q192 && q192_preferred(p)) return launch_gemm_q192(p, stream, 0);
@@ -547,7 +551,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
     // short-K layers (decoder ConvT: K = 128 / 256) are all prologue + epilogue: two 128x128 workgroups per CU overlap each
     // other's store tail, one 256x256 workgroup cannot (SRH_GEMM_SHORTK256=1 restores the old choice)
-    static const bool shortk256 = getenv("SRH_GEMM_SHORTK256") && atoi(getenv("SRH_GEMM_SHORTK256")) == 1;
+    const bool shortk256 = false;
     const bool short_k = p.K <= 256 && !shortk256 && variant < 20;
     if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && !short_k && (fits256 || variant >= 20)) {
         const dim3 g256(((p.M + 255) / 256) * (p.N / 256));

@@ -430,6 +430,8 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+#ifdef SRH_TUNING      // ablation / schedule variants: probe builds only (tools/probes/build_probes.sh); several of them change the RESULT
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<1, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<2, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
@@ -438,31 +440,37 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<5, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+#endif
         attr_set = true;
     }
-    if (ablation == 1) hipLaunchKernelGGL((gemm_q192_kernel<1, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 2) hipLaunchKernelGGL((gemm_q192_kernel<2, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 3) hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 4) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 5) hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 6) hipLaunchKernelGGL((gemm_q192_kernel<4, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 7) hipLaunchKernelGGL((gemm_q192_kernel<5, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 8) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 2>), dim3(grid), dim3(512), Q_LDS, stream, p);
-    else if (ablation == 9) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p);
+#ifdef SRH_TUNING
+    if (ablation == 1) { hipLaunchKernelGGL((gemm_q192_kernel<1, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 2) { hipLaunchKernelGGL((gemm_q192_kernel<2, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 3) { hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 4) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 5) { hipLaunchKernelGGL((gemm_q192_kernel<3, ACT, BIAS, 1>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 6) { hipLaunchKernelGGL((gemm_q192_kernel<4, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 7) { hipLaunchKernelGGL((gemm_q192_kernel<5, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 8) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 2>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 9) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 10) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+#endif
+    (void)ablation;
     // default: the GELU layer (fc1) takes the woven schedule (SCH 3: two epilogue VALU per MFMA gap; measured -3 % on fc1,
     // profiles/r02_gemm_q192_weave.txt), the layers without activation gain nothing from it
-    else if (ACT == 1) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p);
+    if (ACT == 1) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p);
     else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p);
 }
 
 int launch_gemm_q192(const GemmParams& p_in, hipStream_t stream, int ablation) {
     if (!q192_supported(p_in)) return -2;
-    static const int env_prio = getenv("SRH_Q192_PRIO") ? atoi(getenv("SRH_Q192_PRIO")) : 0;
     GemmParams p = p_in;
+#ifdef SRH_TUNING
+    static const int env_prio = getenv("SRH_Q192_PRIO") ? atoi(getenv("SRH_Q192_PRIO")) : 0;
     if (!p.prio_mode) p.prio_mode = env_prio;
     static const int env_gr = getenv("SRH_Q192_GR") ? atoi(getenv("SRH_Q192_GR")) : 0;
     if (!p.tile_gr) p.tile_gr = env_gr;
+#endif
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0; hipDeviceProp_t prop;

@@ -1,12 +1,18 @@
 #!/bin/bash
-# Build the standalone kernel probes against the library's object files (run after `python -m sam_road_amd.build`).
+# Build the standalone kernel probes.  The GEMM probe links its OWN objects of the product's GEMM sources compiled with
+# -DSRH_TUNING, which enables the kernel / ablation selection by number (SRH_GEMM_VARIANT, GemmParams::variant), the q192
+# schedule variants and SRH_Q192_GR / SRH_Q192_PRIO — none of which exist in libsamroad_hip.so.
 set -e
 cd "$(dirname "$0")/../.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-for p in gemm_probe; do
-  $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -c tools/probes/$p.hip -o sam_road_amd/build/$p.o
-  $HIPCC --offload-arch=gfx950 sam_road_amd/build/$p.o sam_road_amd/build/gemm.o sam_road_amd/build/gemm_q192.o -o tools/probes/$p
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING"
+mkdir -p tools/probes/build
+for f in gemm gemm_q192; do
+  $HIPCC $FLAGS -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
 done
+$HIPCC $FLAGS -c tools/probes/gemm_probe.hip -o tools/probes/build/gemm_probe.o &
+wait
+$HIPCC --offload-arch=gfx950 tools/probes/build/gemm_probe.o tools/probes/build/gemm.o tools/probes/build/gemm_q192.o -o tools/probes/gemm_probe
 for p in feed_probe pipe_probe mfma_probe dma_probe; do
   [ -f tools/probes/$p.hip ] && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p
 done

@@ -93,3 +93,26 @@ def test_infer_one_img_end_to_end(pair):
     assert {e for e in ref if e in firm} == {e for e in got if e in firm}
     assert len(got ^ ref) <= max(2, 0.02 * len(ref))
     assert len(sums_r) > 50
+
+
+def test_infer_imgs_pipeline_equals_serial(pair):
+    """The software-pipelined scene loop (infer_imgs: side-stream uploads from page-locked staging, asynchronous mask / score
+    downloads behind events, pass 1 of the next scene queued before this scene's host stages) returns exactly what infer_one_img
+    returns for every scene — five different scenes, so both staging pools are reused and results of neighbouring scenes would
+    show up as differences if a buffer were recycled too early."""
+    from sam_road_amd import Config
+    from sam_road_amd.inferencer import infer_imgs, infer_one_img
+    _, net = pair
+    imgs = [synth_scene(SCENE, seed=s) for s in (6, 7, 8, 9, 10)]
+    _, _, kp0, road0 = infer_one_img(net, imgs[0], Config(dict(CFG)))
+    cfg = Config(dict(CFG, ITSC_THRESHOLD=float(np.percentile(kp0[kp0 > 0], 99.5)) / 255.0,
+                      ROAD_THRESHOLD=float(np.percentile(road0[road0 > 0], 98.0)) / 255.0))
+    want = [infer_one_img(net, im, cfg) for im in imgs]
+    print("points / edges per scene:", [(w[0].shape[0], w[1].shape[0]) for w in want])
+    assert len({w[0].shape[0] for w in want}) > 1 and min(w[0].shape[0] for w in want) > 20 and max(w[1].shape[0] for w in want) > 20
+    for _ in range(2):
+        got = list(infer_imgs(net, iter(imgs), cfg))
+        assert len(got) == len(want)
+        for w, g in zip(want, got):
+            for a, b in zip(w, g):
+                np.testing.assert_array_equal(np.asarray(a), np.asarray(b))

@@ -2,8 +2,9 @@
 """Scene-level timing (BASELINE configs[3], one GPU): one synthetic 2048x2048 u8 scene (2 km x 2 km at 1 m/px),
 toponet_vitb_512_cityscale.yaml tiling (SAMPLE_MARGIN 64, 16x16 = 256 tiles of 512^2), seeded random weights.
 Reports ms per scene for pass 1 alone (crop -> encoder -> decoder -> fused u8 masks, all on the GPU) and for the
-whole infer_one_img (pass 1 + host NMS + pass-2 queries + TopoNet + edge vote).  The final map_decoder bias is
-lowered so that the random network yields sparse masks (a few thousand graph points, as a trained one does).
+whole infer_one_img (pass 1 + host NMS + pass-2 queries + TopoNet + edge vote) = the latency of one scene, and for a run of
+scenes through infer_imgs (the CLI's loop: scene i's host stages overlap scene i+1's pass 1) = the throughput figure.
+The final map_decoder bias is lowered so that the random network yields sparse masks (a few thousand graph points, as a trained one does).
 
     python tools/scene_bench.py [--bias -2.2] [--wscale 16] [--batch 64] [--iters 3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/scene_bench.py    # N GPUs:
@@ -88,6 +89,7 @@ def main():
             acc[name] += time.perf_counter() - t
             return r
         return w
+    plain = inf.extract_graph_points, inf.edge_votes
     inf.extract_graph_points = timed("extract_graph_points", inf.extract_graph_points)
     inf.edge_votes = timed("edge_votes", inf.edge_votes)
     res = infer_one_img(net, img, cfg)
@@ -98,6 +100,19 @@ def main():
         res = infer_one_img(net, img, cfg)
     torch.cuda.synchronize()
     full = (time.perf_counter() - t0) / args.iters
+    # throughput of the CLI's scene loop: the same scenes through the software-pipelined generator (one GPU only; the timed
+    # region covers n scenes from the first upload to the last edge list, so the pipeline's fill and drain are included)
+    piped, same = None, None
+    inf.extract_graph_points, inf.edge_votes = plain            # the timing wrappers synchronise the device
+    if world == 1:
+        n = max(args.iters, 2) * 4
+        list(inf.infer_imgs(net, (img for _ in range(3)), cfg))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = list(inf.infer_imgs(net, (img for _ in range(n)), cfg))
+        torch.cuda.synchronize()
+        piped = (time.perf_counter() - t0) / n
+        same = all(all(np.array_equal(a, b) for a, b in zip(o, res)) for o in outs)
     if world > 1:
         t = torch.tensor([p1, full], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -110,6 +125,7 @@ def main():
     print(json.dumps({"scene": "synthetic 2048x2048 u8, 256 tiles of 512^2 (16x16, margin 64)", "n_gpus": world,
                       "infer_batch_size": args.batch, "ms_per_scene_pass1": round(1e3 * p1, 2),
                       "tiles_per_s_pass1": round(256 / p1, 1), "ms_per_scene_full": round(1e3 * full, 2),
+                      "ms_per_scene_pipelined": None if piped is None else round(1e3 * piped, 2), "pipelined_equals_serial": same,
                       "ms_extract_graph_points": round(1e3 * acc["extract_graph_points"] / args.iters, 2),
                       "ms_edge_votes": round(1e3 * acc["edge_votes"] / args.iters, 2), "graph_points": int(nodes.shape[0]), "edges": int(edges.shape[0]),
                       "kp_mask_frac": float((kp > cfg.ITSC_THRESHOLD * 255).mean()),

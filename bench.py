@@ -204,7 +204,9 @@ def main():
             phys = psutil.cpu_count(logical=False) or os.cpu_count()
         except Exception:
             phys = os.cpu_count()
-        threads = max(1, min(int(phys), 64))
+        from sam_road_amd.hostcpu import usable_cpus
+        usable = usable_cpus()                  # affinity mask and cgroup CPU quota: more threads than that only get throttled
+        threads = max(1, min(int(phys), 64, usable))
         prev_threads = torch.get_num_threads()
         torch.set_num_threads(threads)
         nt = 4
@@ -218,7 +220,7 @@ def main():
         dt = time.perf_counter() - t0
         torch.set_num_threads(prev_threads)
         out["cpu_baseline"] = {"value": round(nt * iters / dt, 3), "unit": "tiles/s", "cores": threads,
-                               "physical_cores": int(phys), "logical_cpus": os.cpu_count(),
+                               "physical_cores": int(phys), "logical_cpus": os.cpu_count(), "usable_cpus": usable,
                                "kind": "port", "sample": f"oracle (plain PyTorch fp32 eager = the reference's op sequence, inferencer.py --device cpu) "
                                                          f"infer_masks_and_img_features on {nt} of the {B} tiles, 1 warm-up + {iters} timed "
                                                          f"iterations, {threads} threads"}

@@ -72,7 +72,11 @@ def synth_tiles(batch, patch, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand((batch, 3, patch + 8, patch + 8), generator=g) * 255.0
     x = torch.nn.functional.avg_pool2d(x, 8, stride=1)[:, :, :patch, :patch]
-    x = (x - x.mean()) * 4.0 + 127.0  # restore contrast lost by the box filter
+    # restore contrast lost by the box filter.  The mean is taken in float64 by numpy (one thread, pairwise): a parallel f32
+    # torch sum depends on the thread count in its last bits, which moved pixels across the .5 rounding boundary — the "same"
+    # seeded tile differed by one u8 level in ~0.4 % of its pixels between an 8-thread and a 16-thread host.
+    mean = float(x.numpy().astype(np.float64).mean())
+    x = (x - mean) * 4.0 + 127.0
     return x.clamp_(0, 255).round_().permute(0, 2, 3, 1).contiguous()
 
 

@@ -1,0 +1,36 @@
+"""How many CPUs the host stages may use.  os.cpu_count() reports the machine (256 logical CPUs on the MI355X hosts), but a
+container usually runs under a cgroup CPU quota (16 CPUs on the measured boxes): a thread pool sized for the machine burns the
+quota in a few milliseconds, the kernel then throttles EVERY thread of the container for the rest of the 100 ms period — and a
+throttled host stops feeding the GPU.  Measured: a single 128-thread OpenMP region per scene stretched pass 1 on the device from
+75 to ~105 ms (profiles/r02_scene_pipeline.txt)."""
+import os
+
+
+def usable_cpus():
+    """min(CPU affinity mask, cgroup v2 / v1 CPU quota), at least 1."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                     # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # v1
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def worker_threads(cap=8):
+    """Thread count for the library's host-side worker pools (srh_pass2_fill): half of the usable CPUs, at most `cap`."""
+    return max(1, min(cap, usable_cpus() // 2))

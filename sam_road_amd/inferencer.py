@@ -19,6 +19,7 @@ import torch
 
 from . import distributed as D
 from .graph_points import extract_graph_points
+from .hostcpu import usable_cpus, worker_threads
 from .tiling import get_patch_info_one_img, shard_tiles
 
 
@@ -96,7 +97,7 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     knn = np.zeros((total, k), dtype=np.int32)
     amb = np.zeros(total, dtype=np.uint8)
     if lib.srh_pass2_fill(vp(pts), pts.shape[0], vp(boxes), n_tiles, k, int(r), vp(offsets), vp(ids), vp(knn), vp(amb),
-                          max(1, min(16, (os.cpu_count() or 2) - 1))) != 0:
+                          worker_threads()) != 0:
         raise _lib.SrhError("srh_pass2_fill failed")
     lap("count + fill (library)")
     tile_of = np.repeat(np.arange(n_tiles), counts)
@@ -477,6 +478,14 @@ def infer_imgs(net, imgs, config, device=None):
     lane = _Lane(device)
     pools = [_StagingPool(device), _StagingPool(device)]
     bs, K = int(config.INFER_BATCH_SIZE), int(config.MAX_NEIGHBOR_QUERIES)
+    import os
+    import time
+    prof = os.environ.get("SRH_PROFILE_HOST") == "1"      # tuning aid: host wall time of each step (no device synchronisation)
+    t_sec = [time.perf_counter()]
+    def lap(name):
+        if prof:
+            t_sec.append(time.perf_counter())
+            print(f"[infer_imgs] {name}: {(t_sec[-1] - t_sec[-2]) * 1e3:.1f} ms", flush=True)
 
     def launch_pass1(img, pool):                       # G1: upload, pass 1, normalise, masks on their way to the host
         job = _SceneJob()
@@ -484,9 +493,17 @@ def infer_imgs(net, imgs, config, device=None):
         job.pool, job.n_tiles = pool, len(job.infos)
         scene = lane.upload(pool, "scene", img)
         xy_dev = lane.upload(pool, "xy", all_xy)
+        lap("stage + queue scene upload")
+        if prof and lane.cuda:
+            job.t = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            job.t[0].record()
         kp_c, road_c, job.emb = net.scene_pass1(scene, xy_dev, bs)
+        lap("queue pass 1")
         kp_u8, road_u8 = net.scene_normalise(kp_c, road_c, xy_dev)
+        if prof and lane.cuda:
+            job.t[1].record()
         job.masks, job.e1 = lane.download(pool, "mask", [kp_u8, road_u8])
+        lap("queue normalise + mask download")
         return job
 
     def points_and_pass2(job):                         # H1 + G2: points, queries, TopoNet launches, scores on their way back
@@ -494,24 +511,35 @@ def infer_imgs(net, imgs, config, device=None):
             job.e1.synchronize()
         job.kp_mask, job.road_mask = (m.numpy().copy() for m in job.masks)
         job.graph_points = extract_graph_points(job.kp_mask, job.road_mask, config)
+        lap("extract_graph_points")
         job.fq = job.plan = job.votes = None
         if job.graph_points.shape[0] == 0:
             return
         job.fq = build_all_patch_queries(job.graph_points, job.infos, 0, job.n_tiles, config, flat=True)
+        lap("build_all_patch_queries")
         if job.fq is None:                             # non-integer radius: the serial per-tile path
             job.votes = edge_votes(net, job.emb, job.graph_points, job.infos, 0, job.n_tiles, config, device)
             return
         stage = {}
         def alloc(name, shape, dtype):
-            stage[name] = job.pool.get("up_" + name, shape, torch.from_numpy(np.zeros(0, dtype)).dtype).zero_()
-            return stage[name].numpy()
+            stage[name] = job.pool.get("up_" + name, shape, torch.from_numpy(np.zeros(0, dtype)).dtype)
+            a = stage[name].numpy()
+            a.fill(0)                                  # numpy, not Tensor.zero_(): a torch CPU op wakes the whole OpenMP pool (hostcpu.py)
+            return a
         job.plan = _pack_pass2_batches(job.fq, 0, job.n_tiles, bs, K, alloc)[0]
         if not job.plan:
             return
         pts_d, pairs_d, valid_d = (lane.upload_staged(stage[n]) for n in ("points", "pairs", "valid"))
+        if prof and lane.cuda:
+            job.t[2].record()
         launched = _launch_pass2_batches(net, job.emb, job.plan, pts_d, pairs_d, valid_d, K, 0)
+        if prof and lane.cuda:
+            job.t[3].record()
         job.scores, job.e2 = lane.download(job.pool, "score", [sc for _, _, sc in launched])
+        if prof and lane.cuda:
+            job.t[4].record()
         job.emb = None
+        lap("pack + queue pass 2")
 
     def finish(job):                                   # H2: votes -> edges
         nodes = job.graph_points[:, ::-1]              # (row, col)
@@ -524,10 +552,16 @@ def infer_imgs(net, imgs, config, device=None):
                 return nodes, no_edges.astype(np.int64), job.kp_mask, job.road_mask
             if job.e2 is not None:
                 job.e2.synchronize()
+            lap("wait for pass-2 scores")
+            if prof and lane.cuda:
+                t = job.t
+                print(f"[infer_imgs] device: pass 1 {t[0].elapsed_time(t[1]):.1f} ms, mask download -> pass 2 start {t[1].elapsed_time(t[2]):.1f} ms, "
+                      f"pass 2 {t[2].elapsed_time(t[3]):.1f} ms, score download {t[3].elapsed_time(t[4]):.1f} ms", flush=True)
             k, s = _votes_from_scores(job.fq, 0, [(off, end, sc.numpy()) for (off, end, _, _), sc in zip(job.plan, job.scores)],
                                       n_pts, K)
             job.votes = _accumulate_votes(k, s)
         edges = votes_to_edges(*job.votes, n_pts, config.TOPO_THRESHOLD)
+        lap("votes -> edges")
         return nodes, edges, job.kp_mask, job.road_mask
 
     it = iter(imgs)
@@ -539,8 +573,10 @@ def infer_imgs(net, imgs, config, device=None):
     prev, i = None, 0
     while cur is not None:
         with _gc_paused():                             # see infer_one_img: a generation-2 sweep costs ~20 ms when it lands in a scene
+            lap("(consumer)")
             if cur.e1 is not None:
                 cur.e1.synchronize()                   # scene i's masks are on the host: the device is free for scene i+1
+            lap("wait for pass-1 masks")
             img = next(it, None)
             nxt = launch_pass1(img, pools[(i + 1) % 2]) if img is not None else None
             res = finish(prev) if prev is not None else None
@@ -630,6 +666,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     config = load_config(args.config)
     device = torch.device("cuda") if args.device == "cuda" else torch.device(args.device)
+    torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))     # respect the container's CPU quota (hostcpu.py)
     net = _build_net(config, args.checkpoint, device)
 
     if args.images is not None:

@@ -110,10 +110,28 @@ def _scene_setup():
     return mg, g, cfg, img
 
 
+def _tied_cutoff_sources(pts, image_size, cfg):
+    """Points whose k-th and (k+1)-th neighbours inside some tile are equidistant (and within the radius): the only queries of
+    inferencer.py:148-176 (per-tile KDTree.query(k + 1, distance_upper_bound)) whose neighbour SET is not fixed by distances."""
+    k, r2 = int(cfg["MAX_NEIGHBOR_QUERIES"]), float(cfg["NEIGHBOR_RADIUS"]) ** 2
+    infos = oscene.get_patch_info_one_img(0, image_size, cfg["SAMPLE_MARGIN"], cfg["PATCH_SIZE"], cfg["INFER_PATCHES_PER_EDGE"])
+    out = set()
+    for _, (x0, y0), (x1, y1) in infos:
+        ids = np.nonzero((pts[:, 0] >= x0) & (pts[:, 0] <= x1) & (pts[:, 1] >= y0) & (pts[:, 1] <= y1))[0]
+        if ids.size <= k + 1:
+            continue
+        p = pts[ids]
+        d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+        np.fill_diagonal(d2, -1)                                   # self is the query's first hit
+        srt = np.sort(d2, axis=1)[:, 1:]                           # distances to the others, ascending
+        out.update(ids[(srt[:, k] == srt[:, k - 1]) & (srt[:, k - 1] < r2)].tolist())
+    return out
+
+
 def test_oracle_infer_one_img_matches_reference_run():
     """oracle/scene.py (tile grid, batcher, fusion, NMS, pass-2 queries, vote) against inferencer.infer_one_img run verbatim:
-    identical u8 masks, identical nodes, identical edge set — for each of the three rtree id orders the fixture was made with
-    (the reference's result does not depend on the order rtree returns ids in; only the edge LIST order does)."""
+    identical u8 masks, identical nodes, identical edge set and edge list order with rtree returning ids ascending; for the two
+    other rtree orders the fixture was made with, identical nodes and an edge set that differs only at tied kNN cut-offs."""
     mg, g, cfg, img = _scene_setup()
     oracle = SAMRoadOracle(AttrDict(cfg)).eval()
     oracle.load_state_dict(mg.scene_state_dict(oracle, mg.SCENE_WSEED), strict=True)
@@ -124,9 +142,15 @@ def test_oracle_infer_one_img_matches_reference_run():
     assert nodes.shape[0] > 100 and edges.shape[0] > 500
     want = {tuple(e) for e in g["edges_ascending"].tolist()}
     assert {tuple(e) for e in edges.tolist()} == want
+    # the other two orders: same nodes; the edge set may differ ONLY at source points whose k-th and (k+1)-th neighbours inside
+    # a tile are equidistant: scipy's kd-tree then keeps whichever it met first (rtree's order decides the tree), and as TopoNet
+    # scores the K pairs of a source jointly, any edge of that source can move across the threshold
+    tied = _tied_cutoff_sources(nodes[:, ::-1].astype(np.int64), img.shape[0], cfg)
     for mode in ("descending", "shuffled"):
         np.testing.assert_array_equal(g[f"nodes_{mode}"], g["nodes_ascending"])
-        assert {tuple(e) for e in g[f"edges_{mode}"].tolist()} == want
+        diff = {tuple(e) for e in g[f"edges_{mode}"].tolist()} ^ want
+        print(f"rtree order {mode}: {len(diff)} of {len(want)} edges differ ({len(tied)} of {nodes.shape[0]} points have a tied cut-off)")
+        assert len(diff) <= 4 * len(tied) and all(e[0] in tied or e[1] in tied for e in diff), diff
     # with ids ascending (the order the oracle's and the product's closed-box filter produce) the edge list order — the
     # insertion order of the reference's dict, inferencer.py:209-228 — is reproduced too
     np.testing.assert_array_equal(edges, g["edges_ascending"])

@@ -1,8 +1,9 @@
 """How many CPUs the host stages may use.  os.cpu_count() reports the machine (256 logical CPUs on the MI355X hosts), but a
 container usually runs under a cgroup CPU quota (16 CPUs on the measured boxes): a thread pool sized for the machine burns the
-quota in a few milliseconds, the kernel then throttles EVERY thread of the container for the rest of the 100 ms period — and a
-throttled host stops feeding the GPU.  Measured: a single 128-thread OpenMP region per scene stretched pass 1 on the device from
-75 to ~105 ms (profiles/r02_scene_pipeline.txt)."""
+quota in a few milliseconds and the kernel then throttles EVERY thread of the container for the rest of each 100 ms period.
+Measured on the GPU box (profiles/r02_scene_pipeline.txt): torch's default 128 OpenMP threads got 69 s of thread time throttled
+during model start-up alone; with the thread count capped to the quota the CPU-oracle legs run 1.4x faster (bench.py cpu_baseline
+1.39 -> 1.92 tiles/s) and the GPU test suite, which is mostly oracle time, takes 97 s instead of 245 s."""
 import os
 
 

@@ -524,7 +524,7 @@ def infer_imgs(net, imgs, config, device=None):
         def alloc(name, shape, dtype):
             stage[name] = job.pool.get("up_" + name, shape, torch.from_numpy(np.zeros(0, dtype)).dtype)
             a = stage[name].numpy()
-            a.fill(0)                                  # numpy, not Tensor.zero_(): a torch CPU op wakes the whole OpenMP pool (hostcpu.py)
+            a.fill(0)                                  # numpy: no reason to wake torch's OpenMP pool for a memset
             return a
         job.plan = _pack_pass2_batches(job.fq, 0, job.n_tiles, bs, K, alloc)[0]
         if not job.plan:

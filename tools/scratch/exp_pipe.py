@@ -24,39 +24,37 @@ net.load_state_dict(sd, strict=True); net.eval().to(dev)
 rng = np.random.default_rng(0)
 img = np.kron(rng.integers(0, 256, size=(256, 256, 3)).astype(np.float32), np.ones((8, 8, 1), np.float32)).astype(np.uint8)
 
+def cpu_snapshot():
+    per = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+            per[tid] = (int(f[11]) + int(f[12])) * 10.0      # utime + stime, ms (CLK_TCK 100)
+        except OSError:
+            pass
+    thr = 0
+    try:
+        for l in open("/sys/fs/cgroup/cpu.stat"):
+            if l.startswith("throttled_usec"): thr = int(l.split()[1]) / 1e3
+    except OSError:
+        pass
+    return per, thr
+
 def run(tag, n=16):
     list(inf.infer_imgs(net, (img for _ in range(3)), cfg))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize(); c0, th0 = cpu_snapshot(); t0 = time.perf_counter()
     list(inf.infer_imgs(net, (img for _ in range(n)), cfg))
     torch.cuda.synchronize()
-    print(f"{tag}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms/scene", flush=True)
+    wall = time.perf_counter() - t0
+    c1, th1 = cpu_snapshot()
+    d = sorted(((c1[k] - c0.get(k, 0.0)) for k in c1), reverse=True)
+    ms_ = torch.cuda.memory_stats()
+    print("   device mallocs so far", ms_.get("num_device_alloc"), "frees", ms_.get("num_device_free"), "reserved MB", ms_.get("reserved_bytes.all.current", 0) >> 20,
+          "active MB", ms_.get("active_bytes.all.current", 0) >> 20)
+    print(f"{tag}: {wall / n * 1e3:.1f} ms/scene | wall {wall*1e3:.0f} ms, cpu {sum(d):.0f} ms over {sum(x > 0 for x in d)} busy threads (top: {[int(x) for x in d[:6]]}), "
+          f"throttled {th1 - th0:.0f} ms, threads alive {len(c1)}", flush=True)
 
-run("as is")
-real_cpu_count = os.cpu_count
-os.cpu_count = lambda: 2
-torch.set_num_threads(1)
-run("1 worker thread in srh_pass2_fill, torch 1 thread")
-os.cpu_count = real_cpu_count
-orig = inf._Lane.upload_staged
-def on_main(self, stage):
-    dst = torch.empty(stage.shape, dtype=stage.dtype, device=self.device)
-    dst.copy_(stage, non_blocking=True)
-    return dst
-inf._Lane.upload_staged = on_main
-run("uploads on the compute stream")
-inf._Lane.upload_staged = orig
-# host stages replaced by sleeps of the same length: does CPU load matter?
-egp, bq = inf.extract_graph_points, inf.build_all_patch_queries
-cache = {}
-def egp_s(*a, **k):
-    if "p" not in cache: cache["p"] = egp(*a, **k)
-    time.sleep(0.012); return cache["p"]
-def bq_s(*a, **k):
-    if "q" not in cache: cache["q"] = bq(*a, **k)
-    time.sleep(0.018); return cache["q"]
-inf.extract_graph_points, inf.build_all_patch_queries = egp_s, bq_s
-run("points + queries replaced by sleeps (cached results)")
-inf.extract_graph_points, inf.build_all_patch_queries = egp, bq
-print("cpu_count", real_cpu_count(), "affinity", len(os.sched_getaffinity(0)))
-for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu.stat"):
-    if os.path.exists(f): print(f, open(f).read().strip().replace("\n", " | "))
+print("torch threads", torch.get_num_threads())
+for rep in range(6):
+    run(f"as is, default torch threads, repetition {rep}", n=12)
+

@@ -462,15 +462,17 @@ def _gc_paused():
     return cm()
 
 
-def infer_imgs(net, imgs, config, device=None):
+def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
     """infer_one_img over a sequence of scenes, as a generator of the same tuples in the same order — software-pipelined on
     one GPU: while the device runs pass 1 of scene i+1, the host does scene i's mask -> points -> pass-2 queries; scene i's
     TopoNet batches are queued behind that pass 1 and its edge vote runs while scene i+2 is on the device.  One compute stream
     (the library context is single-stream), one copy stream, events instead of device-wide synchronisation; every scene's
     canvases / embeddings are its own tensors, so nothing of the context is double-buffered.  The results are those of
     infer_one_img bit for bit (same kernels in the same order per scene).  The reference's loop (inferencer.py:289-349) is
-    strictly serial; this is what the CLI uses.  With torch.distributed initialised it falls back to the per-scene sharded path."""
-    if D.is_distributed():
+    strictly serial; this is what the CLI uses.  tile_sharded (default: torch.distributed is initialised) selects the other
+    multi-GPU mode instead — every scene's tiles split over the ranks through infer_one_img, one scene at a time; with
+    tile_sharded=False each rank runs its own scenes through the pipeline and no collective is issued."""
+    if D.is_distributed() if tile_sharded is None else tile_sharded:
         for img in imgs:
             yield infer_one_img(net, img, config, device)
         return
@@ -649,7 +651,9 @@ def main(argv=None):
     save/<output_dir>/{config.yaml, mask/{id}_road.png, mask/{id}_itsc.png, graph/{id}.p, inference_time.txt} with the
     reference's formats (8-bit grayscale PNG masks, sat2graph pickle, SpaceNet (400 - r, c) flip).  Not reproduced: the cv2
     `viz/` renderings and the ground-truth pickle the reference loads but only uses in commented-out code (visualisation,
-    SURVEY §2 #17).  Extra: `--images a.png b.npy ...` runs explicit scene files instead of the dataset split."""
+    SURVEY §2 #17).  Extras: `--images a.png b.npy ...` runs explicit scene files instead of the dataset split; under torchrun
+    (one process per GPU) the scenes are dealt round-robin to the ranks (`--shard scenes`, default) or every scene's tiles are split
+    over the ranks (`--shard tiles`), all ranks writing into the one output directory."""
     import argparse
     import os
     import pickle
@@ -663,10 +667,26 @@ def main(argv=None):
     ap.add_argument("--output_dir", default=None, help="Name of the output dir, if not specified will use timestamp")
     ap.add_argument("--device", default="cuda", help="device to use (an MI355X: there is no CPU path)")
     ap.add_argument("--images", nargs="*", default=None, help="(extension) explicit scene images instead of the dataset split")
+    ap.add_argument("--shard", choices=("scenes", "tiles"), default="scenes",
+                    help="(extension, multi-GPU runs under torchrun) scenes: every rank takes whole scenes, no data-path collective "
+                         "(throughput); tiles: the tiles of every scene are split over the ranks (latency of one scene)")
     args = ap.parse_args(argv)
     config = load_config(args.config)
     device = torch.device("cuda") if args.device == "cuda" else torch.device(args.device)
     torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))     # respect the container's CPU quota (hostcpu.py)
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    dist = torch.distributed
+    if world > 1:                                # one process per GPU (torchrun); the reference is single-process (inferencer.py:243)
+        if device.type == "cuda":
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if device.type == "cuda":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group("gloo")
+    by_scene = world > 1 and args.shard == "scenes"
     net = _build_net(config, args.checkpoint, device)
 
     if args.images is not None:
@@ -679,15 +699,25 @@ def main(argv=None):
         jobs = [(i, "./spacenet/RGB_1.0_meter/{}__rgb.png".format(i)) for i in test_img_indices]
     else:
         raise ValueError(f"config.DATASET must be 'cityscale' or 'spacenet' (got {config.DATASET!r}), or pass --images")
+    if by_scene:
+        jobs = jobs[rank::world]                 # independent scenes: round-robin over the ranks, nothing to exchange
 
     output_dir_prefix = "./save/infer_"
-    if args.output_dir:
+    if world > 1:                                # one directory for all ranks: rank 0 creates it (and its timestamp), the others wait
+        name = [None]
+        if rank == 0:
+            name[0] = create_output_dir_and_save_config(output_dir_prefix, config,
+                                                        specified_dir=f"./save/{args.output_dir}" if args.output_dir else None)
+        dist.broadcast_object_list(name, src=0)
+        output_dir = name[0]
+    elif args.output_dir:
         output_dir = create_output_dir_and_save_config(output_dir_prefix, config, specified_dir=f"./save/{args.output_dir}")
     else:
         output_dir = create_output_dir_and_save_config(output_dir_prefix, config)
 
+    from concurrent.futures import ThreadPoolExecutor
+
     def scenes():                                # decode the next image on a worker thread while the current one is on the GPU
-        from concurrent.futures import ThreadPoolExecutor
         load = lambda path: np.load(path) if str(path).endswith(".npy") else read_rgb_img(path)
         with ThreadPoolExecutor(1) as ex:
             futs = [ex.submit(load, jobs[0][1])] if jobs else []
@@ -697,35 +727,48 @@ def main(argv=None):
                 yield futs[j].result()
                 futs[j] = None
 
-    # the reference times infer_one_img per image (inferencer.py:292-296); the scenes are software-pipelined here (infer_imgs), so
-    # the time reported is what the loop spends waiting for results — its sum over the images is the wall time of inference
-    total_inference_seconds = 0.0
-    results = infer_imgs(net, scenes(), config)
-    for img_id, path in jobs:
-        print(f"Processing {img_id}")
-        start_seconds = time.time()
-        res = next(results)
-        total_inference_seconds += time.time() - start_seconds
-        if res is None:                      # non-zero rank of a multi-GPU run
-            continue
-        pred_nodes, pred_edges, itsc_mask, road_mask = res
-        mask_save_dir = os.path.join(output_dir, "mask")
+    mask_save_dir, graph_save_dir = os.path.join(output_dir, "mask"), os.path.join(output_dir, "graph")
+
+    def write_outputs(img_id, pred_nodes, pred_edges, itsc_mask, road_mask):     # inferencer.py:299-349 minus the cv2 renderings
         os.makedirs(mask_save_dir, exist_ok=True)
         Image.fromarray(road_mask).save(os.path.join(mask_save_dir, f"{img_id}_road.png"))
         Image.fromarray(itsc_mask).save(os.path.join(mask_save_dir, f"{img_id}_itsc.png"))
         if config.DATASET == "spacenet":
             pred_nodes = np.stack([400 - pred_nodes[:, 0], pred_nodes[:, 1]], axis=1)   # inferencer.py:332-334
-        graph_save_dir = os.path.join(output_dir, "graph")
         os.makedirs(graph_save_dir, exist_ok=True)
         with open(os.path.join(graph_save_dir, f"{img_id}.p"), "wb") as f:
             pickle.dump(convert_to_sat2graph_format(pred_nodes, pred_edges), f)
         print(f"Done for {img_id}.")
 
+    # the reference times infer_one_img per image (inferencer.py:292-296); the scenes are software-pipelined here (infer_imgs), so
+    # the time reported is what the loop spends waiting for results — its sum over the images is the wall time of inference.  PNG
+    # encoding and pickling (tens of ms per 2048^2 scene) run on a writer thread so that the loop goes straight back to the GPU.
+    total_inference_seconds = 0.0
+    results = infer_imgs(net, scenes(), config, device=device, tile_sharded=world > 1 and not by_scene)
+    with ThreadPoolExecutor(1) as writer:
+        pending = []
+        for img_id, path in jobs:
+            print(f"Processing {img_id}")
+            start_seconds = time.time()
+            res = next(results)
+            total_inference_seconds += time.time() - start_seconds
+            if res is None:                      # non-zero rank of a tile-sharded run
+                continue
+            pending.append(writer.submit(write_outputs, img_id, *res))
+        for f in pending:
+            f.result()
+
+    if world > 1:                                # the slowest rank is the wall time of the run
+        t = torch.tensor([total_inference_seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total_inference_seconds = float(t.item())
     time_txt = f"Inference completed for {args.config} in {total_inference_seconds} seconds."
     print(time_txt)
-    if not D.is_distributed() or torch.distributed.get_rank() == 0:
+    if rank == 0:
         with open(os.path.join(output_dir, "inference_time.txt"), "w") as f:
             f.write(time_txt)
+    if world > 1:
+        dist.barrier()
 
 
 if __name__ == "__main__":

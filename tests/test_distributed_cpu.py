@@ -232,3 +232,67 @@ def test_infer_imgs_pipeline_matches_infer_one_img():
         for a, b in zip(w, g):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
             assert np.asarray(a).dtype == np.asarray(b).dtype
+
+
+def _cli_rank(world, rank, port, work, out):
+    """One rank of `torchrun ... -m sam_road_amd.inferencer --shard scenes` (gloo, CPU): the model is replaced by a function of
+    the image, so this checks the multi-process plumbing of the CLI only."""
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.chdir(work)
+        from sam_road_amd import inferencer as inf
+        seen = []
+
+        def fake_infer_imgs(net, imgs, config, device=None, tile_sharded=None):
+            assert tile_sharded is False                      # scene sharding: no collective on the data path
+            for im in imgs:
+                seen.append(int(im[:8, :8].astype(np.int64).sum()))
+                nodes = np.array([[1, 2], [3, 4], [int(im[0, 0, 0]), 7]], dtype=np.int64)
+                yield nodes, np.array([[0, 1], [1, 2]], dtype=np.int64), im[:, :, 0].copy(), im[:, :, 1].copy()
+        inf.infer_imgs = fake_infer_imgs
+        inf._build_net = lambda config, checkpoint, device: None
+        inf.main(["--config", "cfg.yaml", "--checkpoint", "ckpt.ckpt", "--output_dir", "run2", "--device", "cpu"])
+        out.put((rank, seen))
+    except Exception:  # pragma: no cover
+        import traceback
+        out.put((rank, "ERR " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_cli_scene_sharding_world2(tmp_path):
+    """The CLI under a 2-process launch, `--shard scenes` (default): ranks take the test scenes round-robin, write into ONE output
+    directory, rank 0 writes config.yaml and inference_time.txt (max over ranks); every scene's files exist exactly once."""
+    import pickle
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_refrun_golden as T
+    g = np.load(f"{T.GOLD}/refrun_cli.npz")
+    work = tmp_path / "cityscale"
+    ids = T._make_fake_dataset(T._mg(), work, "cityscale", g)
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_cli_rank, args=(2, r, port, str(work), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for r, v in got.items():
+        assert not isinstance(v, str), v
+    assert len(got[0]) == len(ids[0::2]) and len(got[1]) == len(ids[1::2])
+    outdir = work / "save" / "run2"
+    files = sorted(os.path.relpath(os.path.join(d, f), outdir) for d, _, fs in os.walk(outdir) for f in fs)
+    want = sorted(["config.yaml", "inference_time.txt"] + [f"mask/{i}_road.png" for i in ids] + [f"mask/{i}_itsc.png" for i in ids]
+                  + [f"graph/{i}.p" for i in ids])
+    assert files == want
+    for j, i in enumerate(ids):                                   # each scene was processed by the rank that owns it, from ITS image
+        src = np.array(Image.open(work / "cityscale" / "20cities" / f"region_{i}_sat.png").convert("RGB"))
+        np.testing.assert_array_equal(np.array(Image.open(outdir / "mask" / f"{i}_itsc.png")), src[:, :, 0])
+        np.testing.assert_array_equal(np.array(Image.open(outdir / "mask" / f"{i}_road.png")), src[:, :, 1])
+        assert int(src[:8, :8].astype(np.int64).sum()) == got[j % 2][j // 2]
+        gr = pickle.load(open(outdir / "graph" / f"{i}.p", "rb"))
+        assert (int(src[0, 0, 0]), 7) in gr
+    assert open(outdir / "inference_time.txt").read().startswith("Inference completed for cfg.yaml in ")

@@ -199,7 +199,7 @@ def test_cli_plumbing_matches_reference_run(tmp_path, monkeypatch):
             edges = np.array([e for e in edges if e[0] < e[1]], dtype=np.int64).reshape(-1, 2)
             return nodes, edges, g[key + "_itsc"], g[key + "_road"]
 
-        monkeypatch.setattr(inf, "infer_imgs", lambda net, imgs, config, _f=fake_infer: (_f(net, im, config) for im in imgs))
+        monkeypatch.setattr(inf, "infer_imgs", lambda net, imgs, config, _f=fake_infer, **kw: (_f(net, im, config) for im in imgs))
         monkeypatch.setattr(inf, "_build_net", lambda config, checkpoint, device: None)
         monkeypatch.chdir(work)
         inf.main(["--config", "cfg.yaml", "--checkpoint", "ckpt.ckpt", "--output_dir", "run1", "--device", "cpu"])

@@ -295,19 +295,51 @@ def votes_to_edges(uk, sums, cnts, first, n_pts, threshold):
     return np.stack([k // n_pts, k % n_pts], axis=1).reshape(-1, 2)
 
 
-def infer_one_img(net, img, config, device=None):
-    """reference inferencer.py:61-234: (pred_nodes (row, col), pred_edges, keypoint_mask u8, road_mask u8) of one scene.  The cyclic
-    garbage collector is paused for the duration of the call: a generation-2 sweep over the interpreter's objects landed inside
-    roughly one scene in four and cost ~20 ms of a ~120 ms scene (profiles/r02_scene_stages.txt); reference counting still frees
-    every array as it goes."""
-    import gc
-    was_enabled = gc.isenabled()
-    gc.disable()
+def _numpy_hugepages(enabled):
+    """numpy's switch for madvise(MADV_HUGEPAGE) on array allocations of 4 MiB and more (NUMPY_MADVISE_HUGEPAGE); returns the
+    previous state, None if this numpy has no such switch."""
     try:
+        from numpy._core.multiarray import _set_madvise_hugepage
+    except ImportError:
+        try:
+            from numpy.core.multiarray import _set_madvise_hugepage
+        except ImportError:
+            return None
+    return bool(_set_madvise_hugepage(bool(enabled)))
+
+
+def _host_quiet():
+    """Context manager around the host stages of a scene.  Two process-wide settings are switched off inside and restored after:
+    * the cyclic garbage collector — cheap insurance against a generation-2 sweep landing inside a scene; reference counting still
+      frees every array as it goes.  (It was introduced for +20-30 ms scenes that turned out to be the second item.)
+    * numpy's transparent-huge-page madvise for large arrays.  Every first touch / split of such a 2 MiB mapping raises an MMU
+      notifier, and the amdgpu driver answers by taking the process's GPU queues off the hardware for 20-30 ms: with the host
+      stages running beside pass 1 (infer_imgs) ONE kernel per scene was frozen for that long during the first ~30 scenes of a
+      process — pass 1 took 105 instead of 75 ms on the device — until the heap had warmed up (profiles/r02_scene_pipeline.txt,
+      rocprofv3 kernel trace); with plain 4 KiB pages the stalls are gone from the first scene on."""
+    import contextlib
+    import gc
+
+    @contextlib.contextmanager
+    def cm():
+        was_gc = gc.isenabled()
+        gc.disable()
+        was_huge = _numpy_hugepages(False)
+        try:
+            yield
+        finally:
+            if was_huge:
+                _numpy_hugepages(True)
+            if was_gc:
+                gc.enable()
+    return cm()
+
+
+def infer_one_img(net, img, config, device=None):
+    """reference inferencer.py:61-234: (pred_nodes (row, col), pred_edges, keypoint_mask u8, road_mask u8) of one scene (with the
+    garbage collector and numpy's huge-page madvise paused for the duration of the call, see _host_quiet)."""
+    with _host_quiet():
         return _infer_one_img(net, img, config, device)
-    finally:
-        if was_enabled:
-            gc.enable()
 
 
 def _scene_plan(img, config):
@@ -446,22 +478,6 @@ class _SceneJob:
     pass
 
 
-def _gc_paused():
-    import contextlib
-    import gc
-
-    @contextlib.contextmanager
-    def cm():
-        was = gc.isenabled()
-        gc.disable()
-        try:
-            yield
-        finally:
-            if was:
-                gc.enable()
-    return cm()
-
-
 def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
     """infer_one_img over a sequence of scenes, as a generator of the same tuples in the same order — software-pipelined on
     one GPU: while the device runs pass 1 of scene i+1, the host does scene i's mask -> points -> pass-2 queries; scene i's
@@ -570,11 +586,11 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
     img = next(it, None)
     if img is None:
         return
-    with _gc_paused():
+    with _host_quiet():
         cur = launch_pass1(img, pools[0])
     prev, i = None, 0
     while cur is not None:
-        with _gc_paused():                             # see infer_one_img: a generation-2 sweep costs ~20 ms when it lands in a scene
+        with _host_quiet():
             lap("(consumer)")
             if cur.e1 is not None:
                 cur.e1.synchronize()                   # scene i's masks are on the host: the device is free for scene i+1
@@ -584,10 +600,10 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
             res = finish(prev) if prev is not None else None
         if prev is not None:
             yield res
-        with _gc_paused():
+        with _host_quiet():
             points_and_pass2(cur)
         prev, cur, i = cur, nxt, i + 1
-    with _gc_paused():
+    with _host_quiet():
         res = finish(prev)
     yield res
 
@@ -674,6 +690,7 @@ def main(argv=None):
     config = load_config(args.config)
     device = torch.device("cuda") if args.device == "cuda" else torch.device(args.device)
     torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))     # respect the container's CPU quota (hostcpu.py)
+    _numpy_hugepages(False)                      # for the whole run: image decoding and output encoding allocate beside the GPU too (_host_quiet)
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     dist = torch.distributed
     if world > 1:                                # one process per GPU (torchrun); the reference is single-process (inferencer.py:243)

@@ -98,12 +98,13 @@ def test_infer_one_img_end_to_end(pair):
 def test_infer_imgs_pipeline_equals_serial(pair):
     """The software-pipelined scene loop (infer_imgs: side-stream uploads from page-locked staging, asynchronous mask / score
     downloads behind events, pass 1 of the next scene queued before this scene's host stages) returns exactly what infer_one_img
-    returns for every scene — five different scenes, so both staging pools are reused and results of neighbouring scenes would
+    returns for every scene — five different scenes of three sizes, so both staging pools are reused and regrown and results of neighbouring scenes would
     show up as differences if a buffer were recycled too early."""
     from sam_road_amd import Config
     from sam_road_amd.inferencer import infer_imgs, infer_one_img
     _, net = pair
-    imgs = [synth_scene(SCENE, seed=s) for s in (6, 7, 8, 9, 10)]
+    # different scene sizes in one run: the staging pools grow and are re-viewed per scene
+    imgs = [synth_scene(size, seed=s) for size, s in ((SCENE, 6), (384, 7), (SCENE, 8), (512, 9), (384, 10))]
     _, _, kp0, road0 = infer_one_img(net, imgs[0], Config(dict(CFG)))
     cfg = Config(dict(CFG, ITSC_THRESHOLD=float(np.percentile(kp0[kp0 > 0], 99.5)) / 255.0,
                       ROAD_THRESHOLD=float(np.percentile(road0[road0 > 0], 98.0)) / 255.0))

@@ -40,6 +40,8 @@ struct NormParams {
     // optional fused residual add: x' = x + delta16 (fp16 [M,D], a GEMM's deferred-epilogue output) is what gets
     // normalised, and is written back to x_out (may alias x) when x_out != nullptr
     const f16* delta16 = nullptr; float* x_out = nullptr;
+    // optional second branch output folded AFTER the first: x' = (x + delta16) + delta16b (needs delta16)
+    const f16* delta16b = nullptr;
 };
 int launch_layernorm(const NormParams& p, hipStream_t s);
 

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     for (int row0 = wave_global * R; row0 < p.M; row0 += n_waves * R) {
         float v[R][EPL];
         f16 dl[R][EPL];                                   // optional fp16 residual-branch output to fold in (dead when unused)
+        f16 dl2[R][EPL];                                  // optional second one (delta16b)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = min(row0 + r, p.M - 1);
@@ -52,6 +53,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
                     } else {
                         const f16x2 t = *reinterpret_cast<const f16x2*>(d + off);
                         dl[r][c * 2 + 0] = t[0]; dl[r][c * 2 + 1] = t[1];
+                    }
+                }
+                if (p.delta16b) {
+                    const f16* d2 = p.delta16b + (size_t)row * p.D;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        const int off = (c * 64 + lane) * VW;
+                        if (VW == 4) {
+                            const f16x4 t = *reinterpret_cast<const f16x4*>(d2 + off);
+                            dl2[r][c * 4 + 0] = t[0]; dl2[r][c * 4 + 1] = t[1]; dl2[r][c * 4 + 2] = t[2]; dl2[r][c * 4 + 3] = t[3];
+                        } else {
+                            const f16x2 t = *reinterpret_cast<const f16x2*>(d2 + off);
+                            dl2[r][c * 2 + 0] = t[0]; dl2[r][c * 2 + 1] = t[1];
+                        }
                     }
                 }
             }
@@ -73,6 +88,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
             if (p.delta16) {                              // x <- x + delta (the residual add the GEMM epilogue no longer does)
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) v[r][e] += (float)dl[r][e];
+                if (p.delta16b) {                         // (x + first) + second: the order in which the reference adds its two branches
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) v[r][e] += (float)dl2[r][e];
+                }
                 if (p.x_out && row < p.M) {
                     float* xo = p.x_out + (size_t)row * p.D;
 #pragma unroll

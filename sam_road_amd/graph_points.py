@@ -58,11 +58,28 @@ def nms_points(points, scores, radius, return_indices=False):
     return pts[kept]
 
 
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(1, thread_name_prefix="srh-points")
+    return _POOL
+
+
+def _mask_points(mask, threshold, radius):
+    cand, sc = points_and_scores_from_mask(mask, threshold)
+    return nms_points(cand, sc, radius)
+
+
 def extract_graph_points(keypoint_mask, road_mask, config):
-    cand, sc = points_and_scores_from_mask(keypoint_mask, config.ITSC_THRESHOLD * 255)
-    kp0 = nms_points(cand, sc, config.ITSC_NMS_RADIUS)
-    cand, sc = points_and_scores_from_mask(road_mask, config.ROAD_THRESHOLD * 255)
-    kp1 = nms_points(cand, sc, config.ROAD_NMS_RADIUS)
+    """graph_extraction.py:130-139.  The two masks are independent until the final merge: the road mask is processed on a worker
+    thread while this thread does the keypoint mask (the library calls and numpy's argsort release the GIL)."""
+    fut = _pool().submit(_mask_points, road_mask, config.ROAD_THRESHOLD * 255, config.ROAD_NMS_RADIUS)
+    kp0 = _mask_points(keypoint_mask, config.ITSC_THRESHOLD * 255, config.ITSC_NMS_RADIUS)
+    kp1 = fut.result()
     cand = np.concatenate([kp0, kp1], axis=0)
     prio = np.concatenate([np.ones(kp0.shape[0]), np.zeros(kp1.shape[0])], axis=0)  # intersections first
     return nms_points(cand, prio, config.ROAD_NMS_RADIUS)

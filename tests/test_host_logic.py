@@ -324,3 +324,33 @@ def test_pass2_votes_match_reference_triple_loop():
     if fq.knn[fq.offsets[t0], 0] >= 0:
         assert lib.srh_pass2_votes(vp(scores), nb, n_max, K, vp(fq.offsets[t0:]), vp(fq.ids), vp(fq.knn), n_pts, vp(keys), vp(votes),
                                    cap, C.byref(c)) != 0
+
+
+def test_hostcpu_and_host_quiet_restore_process_state():
+    """usable_cpus() never exceeds the affinity mask; _host_quiet() switches the garbage collector and numpy's huge-page madvise off
+    inside and restores exactly the previous state (also when the body raises, and when they were already off)."""
+    import gc
+    import os
+    from sam_road_amd import inferencer as inf
+    from sam_road_amd.hostcpu import usable_cpus, worker_threads
+    n = usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0)) and 1 <= worker_threads() <= max(1, n // 2) and worker_threads(cap=2) <= 2
+    was = inf._numpy_hugepages(True)                       # known starting point
+    assert was in (True, False)
+    try:
+        assert gc.isenabled()
+        with inf._host_quiet():
+            assert not gc.isenabled() and inf._numpy_hugepages(False) is False
+        assert gc.isenabled() and inf._numpy_hugepages(True) is True
+        with pytest.raises(RuntimeError):
+            with inf._host_quiet():
+                raise RuntimeError("x")
+        assert gc.isenabled() and inf._numpy_hugepages(True) is True
+        gc.disable()
+        inf._numpy_hugepages(False)
+        with inf._host_quiet():
+            pass
+        assert not gc.isenabled() and inf._numpy_hugepages(False) is False      # stays off if it was off
+    finally:
+        gc.enable()
+        inf._numpy_hugepages(was)

@@ -59,6 +59,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # host threads: this process's share of the CPUs the container may use (cgroup quota / affinity, sam_road_amd/hostcpu.py) —
+    # torch's default of one OpenMP thread per machine core gets a container throttled during weight initialisation
+    from sam_road_amd.hostcpu import usable_cpus
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // world)))
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -689,7 +689,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     config = load_config(args.config)
     device = torch.device("cuda") if args.device == "cuda" else torch.device(args.device)
-    torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))     # respect the container's CPU quota (hostcpu.py)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))   # this rank's share of the container's CPU quota (hostcpu.py)
     _numpy_hugepages(False)                      # for the whole run: image decoding and output encoding allocate beside the GPU too (_host_quiet)
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     dist = torch.distributed

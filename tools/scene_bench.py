@@ -41,7 +41,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     from sam_road_amd.hostcpu import usable_cpus
-    torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))      # as the CLI does: respect the container's CPU quota
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // world)))      # as the CLI does: respect the container's CPU quota
     cfg = Config(SAM_VERSION="vit_b", PATCH_SIZE=512, TOPONET_VERSION="normal", SAM_CKPT_PATH="", DATASET="cityscale",
                  INFER_BATCH_SIZE=args.batch, SAMPLE_MARGIN=64, INFER_PATCHES_PER_EDGE=16, ITSC_THRESHOLD=0.248,
                  ROAD_THRESHOLD=0.364, TOPO_THRESHOLD=0.499, ITSC_NMS_RADIUS=8, ROAD_NMS_RADIUS=16, NEIGHBOR_RADIUS=64,

@@ -734,35 +734,39 @@ def main(argv=None):
 
     from concurrent.futures import ThreadPoolExecutor
 
-    def scenes():                                # decode the next image on a worker thread while the current one is on the GPU
-        load = lambda path: np.load(path) if str(path).endswith(".npy") else read_rgb_img(path)
-        with ThreadPoolExecutor(1) as ex:
-            futs = [ex.submit(load, jobs[0][1])] if jobs else []
+    def scenes(depth=3):                         # decode ahead on worker threads: a 2048^2 RGB PNG takes ~100 ms to decode, more than
+        load = lambda path: np.load(path) if str(path).endswith(".npy") else read_rgb_img(path)   # the GPU needs for the scene
+        with ThreadPoolExecutor(depth) as ex:
+            futs = {}
             for j in range(len(jobs)):
-                if j + 1 < len(jobs):
-                    futs.append(ex.submit(load, jobs[j + 1][1]))
-                yield futs[j].result()
-                futs[j] = None
+                for k in range(j, min(j + depth, len(jobs))):
+                    if k not in futs:
+                        futs[k] = ex.submit(load, jobs[k][1])
+                yield futs.pop(j).result()
 
     mask_save_dir, graph_save_dir = os.path.join(output_dir, "mask"), os.path.join(output_dir, "graph")
 
-    def write_outputs(img_id, pred_nodes, pred_edges, itsc_mask, road_mask):     # inferencer.py:299-349 minus the cv2 renderings
-        os.makedirs(mask_save_dir, exist_ok=True)
-        Image.fromarray(road_mask).save(os.path.join(mask_save_dir, f"{img_id}_road.png"))
-        Image.fromarray(itsc_mask).save(os.path.join(mask_save_dir, f"{img_id}_itsc.png"))
+    os.makedirs(mask_save_dir, exist_ok=True)
+    os.makedirs(graph_save_dir, exist_ok=True)
+
+    def write_png(mask, name):
+        # zlib level 1 = cv2.imwrite's default for PNG (the reference, inferencer.py:303-304); PIL's default level 6 takes ~50 ms per
+        # 2048^2 mask — two masks per scene would make the encoder, not the GPU, the bottleneck of the loop.  Same pixels either way.
+        Image.fromarray(mask).save(os.path.join(mask_save_dir, name), compress_level=1)
+
+    def write_graph(img_id, pred_nodes, pred_edges):                             # inferencer.py:330-343
         if config.DATASET == "spacenet":
             pred_nodes = np.stack([400 - pred_nodes[:, 0], pred_nodes[:, 1]], axis=1)   # inferencer.py:332-334
-        os.makedirs(graph_save_dir, exist_ok=True)
         with open(os.path.join(graph_save_dir, f"{img_id}.p"), "wb") as f:
             pickle.dump(convert_to_sat2graph_format(pred_nodes, pred_edges), f)
         print(f"Done for {img_id}.")
 
     # the reference times infer_one_img per image (inferencer.py:292-296); the scenes are software-pipelined here (infer_imgs), so
     # the time reported is what the loop spends waiting for results — its sum over the images is the wall time of inference.  PNG
-    # encoding and pickling (tens of ms per 2048^2 scene) run on a writer thread so that the loop goes straight back to the GPU.
+    # encoding and pickling (tens of ms per 2048^2 scene) run on two writer threads so that the loop goes straight back to the GPU.
     total_inference_seconds = 0.0
     results = infer_imgs(net, scenes(), config, device=device, tile_sharded=world > 1 and not by_scene)
-    with ThreadPoolExecutor(1) as writer:
+    with ThreadPoolExecutor(2) as writer:
         pending = []
         for img_id, path in jobs:
             print(f"Processing {img_id}")
@@ -771,7 +775,9 @@ def main(argv=None):
             total_inference_seconds += time.time() - start_seconds
             if res is None:                      # non-zero rank of a tile-sharded run
                 continue
-            pending.append(writer.submit(write_outputs, img_id, *res))
+            pred_nodes, pred_edges, itsc_mask, road_mask = res
+            pending += [writer.submit(write_png, road_mask, f"{img_id}_road.png"), writer.submit(write_png, itsc_mask, f"{img_id}_itsc.png"),
+                        writer.submit(write_graph, img_id, pred_nodes, pred_edges)]
         for f in pending:
             f.result()
 

@@ -32,10 +32,10 @@ def main():
     bad, t0 = 0, time.time()
     nets = {}
 
-    def pair(P, ver, gidx):
-        key = (P, ver, tuple(gidx))
+    def pair(P, ver, gidx, sam="vit_b"):
+        key = (P, ver, tuple(gidx), sam)
         if key not in nets:
-            cfg = dict(SAM_VERSION="vit_b", PATCH_SIZE=P, TOPONET_VERSION=ver, SAM_CKPT_PATH="", ENCODER_DEPTH=2,
+            cfg = dict(SAM_VERSION=sam, PATCH_SIZE=P, TOPONET_VERSION=ver, SAM_CKPT_PATH="", ENCODER_DEPTH=2,
                        ENCODER_GLOBAL_ATTN_INDEXES=list(gidx))
             o = SAMRoadOracle(AttrDict(cfg)).eval()
             sd = synth_state_dict(o, 1000 + len(nets))
@@ -49,8 +49,11 @@ def main():
         P = int(rng.choice([256, 256, 512]))
         ver = str(rng.choice(["normal", "no_offset", "no_transformer", "no_tgt_features"]))
         gidx = [int(rng.integers(0, 2))]
-        cfg, oracle, net = pair(P, ver, gidx)
-        if c % 4 != 3:
+        sam = "vit_b"
+        if c % 6 == 5:                                           # ViT-L / ViT-H widths (head dim 64 x 16 heads / 80 x 16 heads): 256 px tiles
+            P, sam = 256, str(rng.choice(["vit_l", "vit_h"]))
+        cfg, oracle, net = pair(P, ver, gidx, sam)
+        if c % 4 != 3 or sam != "vit_b":
             B = int(rng.choice([1, 2, 3, 5, 7])) if P == 512 else int(rng.choice([1, 2, 3, 5, 9, 17]))
             npts = int(rng.choice([1, 2, 17, 40, 96]))
             rgb = synth_tiles(B, P, seed=int(rng.integers(1 << 30)))
@@ -63,7 +66,7 @@ def main():
             d_s = (ms - ms_r).abs().max().item()
             d_t = (ts[v] - ts_r[v]).abs().max().item() if v.any() else 0.0
             ok = d_s < 2e-2 and d_t < 2e-2 and torch.isfinite(ml).all() and torch.isfinite(tl[v]).all()
-            print(f"case {c:3d} forward P={P} {ver:16s} global={gidx} B={B:2d} N={npts:3d}: mask {d_s:.1e} topo {d_t:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+            print(f"case {c:3d} forward {sam} P={P} {ver:16s} global={gidx} B={B:2d} N={npts:3d}: mask {d_s:.1e} topo {d_t:.1e} {'ok' if ok else 'FAIL'}", flush=True)
         else:
             S = P + 2 * 16 + int(rng.integers(0, 5)) * 24
             scfg = dict(cfg, INFER_BATCH_SIZE=int(rng.choice([1, 3, 5, 8])), SAMPLE_MARGIN=16, INFER_PATCHES_PER_EDGE=int(rng.choice([2, 3])),

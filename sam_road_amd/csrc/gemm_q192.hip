@@ -218,10 +218,13 @@ void gemm_q192_kernel(GemmParams p) {
     const f16x4 r_ = {(f16)v_[0], (f16)v_[1], (f16)v_[2], (f16)v_[3]}; \
     r = __builtin_bit_cast(v2i, r_); }
     // ... and store half (issued in the NEXT ds_read/DMA segment, right after its counted wait)
+#ifndef Q_STORE_AUX
+#define Q_STORE_AUX 0        // cache-policy bits of the deferred-epilogue stores (probe builds try sc0 / nt: tools/probes)
+#endif
 #define Q_EPI_STORE(I, r) { \
     int sb_ = p_soff; \
     asm volatile("" : "+s"(sb_)); \
-    if (ABL != 1) __builtin_amdgcn_raw_buffer_store_b64(r, rsO, vO, sb_ + ((I) / 3) * ld16 + ((I) % 3) * 32, 0); }
+    if (ABL != 1) __builtin_amdgcn_raw_buffer_store_b64(r, rsO, vO, sb_ + ((I) / 3) * ld16 + ((I) % 3) * 32, Q_STORE_AUX); }
 
     // ABL == 3: waves 0 and 4 of workgroup 0 accumulate s_memtime deltas per segment part (dbg[wave>>2][phase][part])
     unsigned long long tsum[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}, tprev = 0;

@@ -177,6 +177,10 @@ int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, int32_t K, c
  * dict, which fixes the order of the pred_edges list (inferencer.py:224-228); out arrays have capacity n. */
 int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys, double* out_sums,
                              double* out_counts, int64_t* out_first, int64_t* n_unique);
+/* The same with n_threads worker threads: the key space is cut into contiguous ranges of equal vote counts (one stable
+ * partition pass), each sorted and accumulated by its own thread; identical outputs, bit for bit. */
+int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys, double* out_sums,
+                                double* out_counts, int64_t* out_first, int64_t* n_unique, int32_t n_threads);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,7 @@ SYMBOLS = {
     "srh_pass2_votes": (_I, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),
     "srh_mask_candidates": (_I, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int64, _P]),
     "srh_edge_vote_accumulate": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "srh_edge_vote_accumulate_mt": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32]),
     "srh_profile_enable": (_I, [_P, _I]),
     "srh_profile_read": (_I, [_P, C.POINTER(ProfileRow), _I, C.POINTER(_I)]),
 }

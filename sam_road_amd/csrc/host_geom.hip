@@ -176,8 +176,55 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
 // to the dict loop.  Outputs (capacity n): unique keys ascending, their sums and counts; *n_unique = how many.
 // scratch: caller-provided, 2 * n int64 + n uint32 is NOT needed — the function allocates its own temporaries.
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
-                                        double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique) {
+namespace {
+
+// stable LSD radix sort of (key, index) pairs by key + the sequential float64 accumulation, on ONE contiguous range of votes.
+// kcur / idx hold the range (n elements), ktmp / tmp are scratch of the same size; bits = key bits to sort on.  Writes the unique
+// keys (ascending), sums, counts and first-vote indices to out_* and returns how many.
+int64_t sort_accumulate_range(int64_t* kcur, uint32_t* idx, int64_t* ktmp, uint32_t* tmp, int64_t n, int64_t kmax, const double* scores,
+                              int64_t* out_keys, double* out_sums, double* out_counts, int64_t* out_first) {
+    // 11-bit digits: 3 passes cover 2^33 (n_points up to ~92k); more passes only if the keys need them.  (Two passes of 13-bit
+    // digits were measured SLOWER, 12.2 vs 6.5 ms per CityScale scene: 8192 scatter streams defeat the write-combining.)
+    const int BITS = 11, RAD = 1 << BITS;
+    uint32_t hist[RAD];
+    for (int shift = 0; shift < 63 && (kmax >> shift) != 0; shift += BITS) {
+        std::fill(hist, hist + RAD, 0u);
+        for (int64_t i = 0; i < n; ++i) ++hist[(size_t)((kcur[i] >> shift) & (RAD - 1))];
+        bool single = false;                              // every key has the same digit (a thread's sub-range of the key space)
+        for (int d = 0; d < RAD; ++d) if (hist[d] == (uint32_t)n) { single = true; break; }
+        if (single) continue;
+        uint32_t run = 0;
+        for (int d = 0; d < RAD; ++d) { const uint32_t c = hist[d]; hist[d] = run; run += c; }
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t k = kcur[i];
+            const uint32_t dst = hist[(size_t)((k >> shift) & (RAD - 1))]++;
+            ktmp[dst] = k;
+            tmp[dst] = idx[i];
+        }
+        std::swap(kcur, ktmp);
+        std::swap(idx, tmp);
+    }
+    int64_t u = -1, prev = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t j = idx[i];
+        const int64_t k = kcur[i];
+        // the sort is stable: the first vote of a run is the key's first visit = its insertion position in the reference's dict
+        if (k != prev) { ++u; out_keys[u] = k; out_sums[u] = 0.0; out_counts[u] = 0.0; if (out_first) out_first[u] = j; prev = k; }
+        out_sums[u] += scores[j];
+        out_counts[u] += 1.0;
+    }
+    return u + 1;
+}
+
+}  // namespace
+
+// n_threads > 1: the key space is cut into n_threads contiguous ranges of (nearly) equal vote counts by one stable partition
+// pass on the keys' top 11 bits (per-thread histograms -> offsets -> scatter), then every thread sorts and accumulates its own
+// range; the ranges' outputs are concatenated in key order.  Inside a key the votes keep their original order, so the sums are
+// the same float64 sums, bit for bit, as with one thread.
+extern "C" int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
+                                           double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique,
+                                           int32_t n_threads) {
     if (n < 0 || !n_unique || (n > 0 && (!keys || !scores || !out_keys || !out_sums || !out_counts))) return SRH_ERR_BAD_ARG;
     *n_unique = 0;
     if (n == 0) return 0;
@@ -187,38 +234,91 @@ extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* score
     // keys travel with their indices, so every pass reads and writes sequentially (an index-only sort gathers keys[idx[i]]
     // at random in each pass: 2x slower on ~500k votes)
     std::vector<uint32_t> idx((size_t)n), tmp((size_t)n);
-    std::vector<int64_t> kcur(keys, keys + n), ktmp((size_t)n);
-    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (uint32_t)i;
-    // 11-bit digits: 3 passes cover 2^33 (n_points up to ~92k); more passes only if the keys need them.  (Two passes of 13-bit
-    // digits were measured SLOWER, 12.2 vs 6.5 ms per CityScale scene: 8192 scatter streams defeat the write-combining.)
-    const int BITS = 11, RAD = 1 << BITS;
-    std::vector<uint32_t> hist((size_t)RAD);
-    for (int shift = 0; shift < 63 && (kmax >> shift) != 0; shift += BITS) {
-        std::fill(hist.begin(), hist.end(), 0u);
-        for (int64_t i = 0; i < n; ++i) ++hist[(size_t)((kcur[(size_t)i] >> shift) & (RAD - 1))];
-        uint32_t run = 0;
-        for (int d = 0; d < RAD; ++d) { const uint32_t c = hist[(size_t)d]; hist[(size_t)d] = run; run += c; }
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t k = kcur[(size_t)i];
-            const uint32_t dst = hist[(size_t)((k >> shift) & (RAD - 1))]++;
-            ktmp[(size_t)dst] = k;
-            tmp[(size_t)dst] = idx[(size_t)i];
+    std::vector<int64_t> kcur((size_t)n), ktmp((size_t)n);
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n / 65536));     // below ~64k votes per thread it does not pay
+    if (T == 1) {
+        std::copy(keys, keys + n, kcur.begin());
+        for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (uint32_t)i;
+        *n_unique = sort_accumulate_range(kcur.data(), idx.data(), ktmp.data(), tmp.data(), n, kmax, scores, out_keys, out_sums,
+                                          out_counts, out_first);
+        return 0;
+    }
+    // ---- partition by the top bits (NB <= 2048 buckets), stable -----------------------------------------------------
+    int kbits = 0;
+    while ((kmax >> kbits) != 0) ++kbits;
+    const int sh = std::max(0, kbits - 11);
+    const int NB = (int)(kmax >> sh) + 1;
+    std::vector<uint32_t> hist((size_t)T * NB, 0u);
+    auto chunk = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back([&, t] {
+            uint32_t* h = hist.data() + (size_t)t * NB;
+            const auto c = chunk(t);
+            for (int64_t i = c.first; i < c.second; ++i) ++h[(size_t)(keys[i] >> sh)];
+        });
+        for (auto& th : pool) th.join();
+    }
+    std::vector<int64_t> bstart((size_t)NB + 1, 0);
+    {
+        int64_t run = 0;
+        for (int b = 0; b < NB; ++b) {
+            bstart[(size_t)b] = run;
+            for (int t = 0; t < T; ++t) { const uint32_t c = hist[(size_t)t * NB + b]; hist[(size_t)t * NB + b] = (uint32_t)run; run += c; }
         }
-        idx.swap(tmp);
-        kcur.swap(ktmp);
+        bstart[(size_t)NB] = run;
     }
-    int64_t u = -1;
-    int64_t prev = -1;
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t j = idx[(size_t)i];
-        const int64_t k = kcur[(size_t)i];
-        // the sort is stable: the first vote of a run is the key's first visit = its insertion position in the reference's dict
-        if (k != prev) { ++u; out_keys[u] = k; out_sums[u] = 0.0; out_counts[u] = 0.0; if (out_first) out_first[u] = j; prev = k; }
-        out_sums[u] += scores[j];
-        out_counts[u] += 1.0;
+    // thread r owns buckets [cut[r], cut[r+1]): contiguous key ranges with ~n / T votes each
+    std::vector<int> cut((size_t)T + 1, NB);
+    cut[0] = 0;
+    for (int r = 1, b = 0; r < T; ++r) {
+        while (b < NB && bstart[(size_t)b] < n * r / T) ++b;
+        cut[(size_t)r] = b;
     }
-    *n_unique = u + 1;
+    std::vector<int64_t> nu((size_t)T, 0);
+    std::vector<std::vector<int64_t>> ok((size_t)T), of((size_t)T);
+    std::vector<std::vector<double>> os((size_t)T), oc((size_t)T);
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back([&, t] {
+            uint32_t* h = hist.data() + (size_t)t * NB;
+            const auto c = chunk(t);
+            for (int64_t i = c.first; i < c.second; ++i) {
+                const int64_t k = keys[i];
+                const uint32_t dst = h[(size_t)(k >> sh)]++;
+                kcur[dst] = k;
+                idx[dst] = (uint32_t)i;
+            }
+        });
+        for (auto& th : pool) th.join();
+    }
+    {
+        std::vector<std::thread> pool;
+        for (int r = 0; r < T; ++r) pool.emplace_back([&, r] {
+            const int64_t lo = bstart[(size_t)cut[(size_t)r]], hi = bstart[(size_t)cut[(size_t)r + 1]], m = hi - lo;
+            if (m <= 0) return;
+            ok[(size_t)r].resize((size_t)m); os[(size_t)r].resize((size_t)m); oc[(size_t)r].resize((size_t)m); of[(size_t)r].resize((size_t)m);
+            nu[(size_t)r] = sort_accumulate_range(kcur.data() + lo, idx.data() + lo, ktmp.data() + lo, tmp.data() + lo, m, kmax, scores,
+                                                  ok[(size_t)r].data(), os[(size_t)r].data(), oc[(size_t)r].data(), of[(size_t)r].data());
+        });
+        for (auto& th : pool) th.join();
+    }
+    int64_t u = 0;
+    for (int r = 0; r < T; ++r) {
+        const size_t m = (size_t)nu[(size_t)r];
+        std::copy(ok[(size_t)r].begin(), ok[(size_t)r].begin() + m, out_keys + u);
+        std::copy(os[(size_t)r].begin(), os[(size_t)r].begin() + m, out_sums + u);
+        std::copy(oc[(size_t)r].begin(), oc[(size_t)r].begin() + m, out_counts + u);
+        if (out_first) std::copy(of[(size_t)r].begin(), of[(size_t)r].begin() + m, out_first + u);
+        u += (int64_t)m;
+    }
+    *n_unique = u;
     return 0;
+}
+
+extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
+                                        double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique) {
+    return srh_edge_vote_accumulate_mt(keys, scores, n, out_keys, out_sums, out_counts, out_first, n_unique, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

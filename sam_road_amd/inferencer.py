@@ -207,7 +207,8 @@ def _accumulate_votes(k, s):
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     uk, sums, cnts, first = np.empty_like(k), np.empty_like(s), np.empty_like(s), np.empty_like(k)
     nu = C.c_int64(0)
-    if _lib.load().srh_edge_vote_accumulate(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), vp(first), C.byref(nu)) != 0:
+    if _lib.load().srh_edge_vote_accumulate_mt(vp(k), vp(s), k.shape[0], vp(uk), vp(sums), vp(cnts), vp(first), C.byref(nu),
+                                               worker_threads()) != 0:
         raise _lib.SrhError("srh_edge_vote_accumulate failed")
     return uk[:nu.value], sums[:nu.value], cnts[:nu.value], first[:nu.value]
 

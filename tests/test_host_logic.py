@@ -354,3 +354,36 @@ def test_hostcpu_and_host_quiet_restore_process_state():
     finally:
         gc.enable()
         inf._numpy_hugepages(was)
+
+
+def test_edge_vote_accumulate_threads_identical():
+    """srh_edge_vote_accumulate_mt with 1 / 3 / 8 worker threads: identical unique keys, float64 sums (bit for bit), counts and
+    first-vote positions — on ~0.7 M votes keyed like a dense scene (src * n + tgt, every key voted ~20 times in scattered order)."""
+    import ctypes as C
+    from sam_road_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n_pts = 5000
+    src = rng.integers(0, n_pts, size=700_000)
+    tgt = (src + rng.integers(1, 17, size=src.shape[0])) % n_pts
+    keys = np.ascontiguousarray(src * n_pts + tgt, dtype=np.int64)
+    scores = np.ascontiguousarray(rng.random(keys.shape[0]), dtype=np.float64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    outs = []
+    for nt in (1, 3, 8):
+        uk, sums, cnts, first = np.empty_like(keys), np.empty_like(scores), np.empty_like(scores), np.empty_like(keys)
+        nu = C.c_int64(0)
+        assert lib.srh_edge_vote_accumulate_mt(vp(keys), vp(scores), keys.shape[0], vp(uk), vp(sums), vp(cnts), vp(first), C.byref(nu), nt) == 0
+        outs.append(tuple(a[:nu.value].copy() for a in (uk, sums, cnts, first)))
+    ref_k, inv = np.unique(keys, return_inverse=True)
+    np.testing.assert_array_equal(outs[0][0], ref_k)
+    np.testing.assert_array_equal(outs[0][2], np.bincount(inv).astype(np.float64))
+    assert np.array_equal(keys[outs[0][3]], ref_k) and (np.diff(outs[0][0]) > 0).all()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert a.dtype == b.dtype and np.array_equal(a, b)        # array_equal on float64: exact
+    # the sums are the sequential float64 sums in vote order
+    want = np.zeros(ref_k.shape[0])
+    for i in np.nonzero(inv < 50)[0]:
+        want[inv[i]] += scores[i]
+    np.testing.assert_array_equal(outs[2][1][:50], want[:50])

@@ -170,6 +170,12 @@ int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float thresho
 int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, int32_t K, const int64_t* offsets, const int64_t* ids,
                     const int32_t* knn, int64_t n_points, int64_t* keys, double* votes, int64_t capacity, int64_t* count);
 
+/* Padded collate of one TopoNet batch (reference inferencer.py:179-185) from the flat arrays of srh_pass2_fill: tile b of the
+ * batch owns rows offsets[b] .. offsets[b+1] of local [*,2] and knn [*,K]; writes points f32 [nb,n_max,2], pairs i32
+ * [nb,n_max,K,2] (source row, target row — the source itself where invalid) and valid u8 [nb,n_max,K], zero beyond a tile's rows. */
+int srh_pass2_pack(const int64_t* offsets, const int64_t* local, const int32_t* knn, int32_t nb, int64_t n_max, int32_t K,
+                   float* points, int32_t* pairs, uint8_t* valid);
+
 /* Directed edge votes of pass 2 (reference inferencer.py:209-221: dict of score sums / counts keyed by (src, tgt), filled in
  * tile / point / slot order).  keys[i] = src * n_points + tgt, scores[i] in that visiting order.  Writes the unique keys in
  * ascending order with their float64 sums — accumulated in the reference's order, hence bit-identical to its loop — and

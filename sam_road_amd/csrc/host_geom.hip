@@ -396,3 +396,37 @@ extern "C" int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, fl
     *n = c;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Padded collate of one TopoNet batch (reference inferencer.py:179-185: graph_collate_fn-style zero padding of the per-tile
+// point / pair / valid arrays to the longest tile) straight from the flat query arrays of srh_pass2_fill: tile b of the batch
+// owns rows offsets[b] .. offsets[b+1] of local [*,2] (tile-local integer x, y) and knn [*,K] (tile-local target or -1).
+// Writes points f32 [nb, n_max, 2], pairs i32 [nb, n_max, K, 2] = (row, target or row itself when invalid) and valid u8
+// [nb, n_max, K]; rows beyond a tile's count are zero.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int srh_pass2_pack(const int64_t* offsets, const int64_t* local, const int32_t* knn, int32_t nb, int64_t n_max, int32_t K,
+                              float* points, int32_t* pairs, uint8_t* valid) {
+    if (!offsets || !local || !knn || !points || !pairs || !valid || nb < 0 || n_max < 0 || K <= 0) return SRH_ERR_BAD_ARG;
+    for (int32_t b = 0; b < nb; ++b) {
+        const int64_t a = offsets[b], n = offsets[b + 1] - a;
+        if (n < 0 || n > n_max) return SRH_ERR_BAD_ARG;
+        float* pt = points + (int64_t)b * n_max * 2;
+        int32_t* pr = pairs + (int64_t)b * n_max * K * 2;
+        uint8_t* vl = valid + (int64_t)b * n_max * K;
+        for (int64_t r = 0; r < n; ++r) {
+            pt[2 * r] = (float)local[2 * (a + r)];
+            pt[2 * r + 1] = (float)local[2 * (a + r) + 1];
+            const int32_t* row = knn + (a + r) * K;
+            for (int32_t j = 0; j < K; ++j) {
+                const bool ok = row[j] >= 0;
+                vl[r * K + j] = ok ? 1 : 0;
+                pr[(r * K + j) * 2] = (int32_t)r;
+                pr[(r * K + j) * 2 + 1] = ok ? row[j] : (int32_t)r;
+            }
+        }
+        std::memset(pt + 2 * n, 0, (size_t)(n_max - n) * 2 * sizeof(float));
+        std::memset(pr + n * K * 2, 0, (size_t)(n_max - n) * K * 2 * sizeof(int32_t));
+        std::memset(vl + n * K, 0, (size_t)(n_max - n) * K);
+    }
+    return 0;
+}

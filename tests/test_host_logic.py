@@ -387,3 +387,28 @@ def test_edge_vote_accumulate_threads_identical():
     for i in np.nonzero(inv < 50)[0]:
         want[inv[i]] += scores[i]
     np.testing.assert_array_equal(outs[2][1][:50], want[:50])
+
+
+def test_pass2_pack_matches_per_tile_collate():
+    """_pack_pass2_batches (srh_pass2_pack on the flat query arrays) == zero-padded collate of the per-tile (points, pairs, valid)
+    tuples (inferencer.py:179-185), for ragged batches incl. an empty tile; the staging arrays may hold garbage beforehand."""
+    from sam_road_amd import Config
+    from sam_road_amd import inferencer as inf
+    from sam_road_amd.tiling import get_patch_info_one_img
+    rng = np.random.default_rng(3)
+    cfg = Config(PATCH_SIZE=256, SAMPLE_MARGIN=16, INFER_PATCHES_PER_EDGE=4, NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16, INFER_BATCH_SIZE=5)
+    infos = get_patch_info_one_img(0, 640, 16, 256, 4)
+    pts = rng.integers(300, 640, size=(400, 2)).astype(np.int64)            # the top-left tiles stay empty
+    pts = pts[np.unique(pts[:, 0] * 1000 + pts[:, 1], return_index=True)[1]]
+    fq = inf.build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+    assert (np.diff(fq.offsets) == 0).any() and (np.diff(fq.offsets) > 20).any()
+    K, bs = 16, 5
+    junk = lambda name, shape, dtype: np.full(shape, 77, dtype)
+    plan, p_h, q_h, v_h = inf._pack_pass2_batches(fq, 0, len(infos), bs, K, junk)
+    assert len(plan) >= 2
+    for off, end, n_max, base in plan:
+        tiles = [fq.tile(t) for t in range(off, end)]
+        sl = slice(base, base + (end - off) * n_max)
+        np.testing.assert_array_equal(p_h[sl].reshape(end - off, n_max, 2), inf._collate([t[1].astype(np.float32) for t in tiles]))
+        np.testing.assert_array_equal(q_h[sl].reshape(end - off, n_max, K, 2), inf._collate([t[2].astype(np.int32) for t in tiles]))
+        np.testing.assert_array_equal(v_h[sl].reshape(end - off, n_max, K), inf._collate([t[3].astype(np.uint8) for t in tiles]))

@@ -20,13 +20,14 @@
 #ifndef SAMROAD_HIP_H
 #define SAMROAD_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 2
+#define SRH_ABI_VERSION 3
 
 typedef enum {
     SRH_OK = 0,
@@ -65,6 +66,10 @@ typedef struct {
 } srh_named_tensor;
 
 int srh_abi_version(void);
+/* 16 hex digits: sha256 over the sources (csrc, this header, compiler flags) the library was built from.  The Python shim,
+ * __graft_entry__.build() / smoke() and bench.py compare it with the hash of the sources in the tree, so a stale prebuilt
+ * library is rebuilt or refused instead of silently measured (the reference has no counterpart: it is interpreted). */
+const char* srh_build_id(void);
 
 /* lifetime ------------------------------------------------------------------------------------ */
 int srh_ctx_create(int device, srh_ctx** out);
@@ -77,6 +82,15 @@ const char* srh_last_error(const srh_ctx* ctx);
 int srh_weights_pack(srh_ctx* ctx, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
                      srh_weights** out);
 void srh_weights_free(srh_weights* w);
+
+/* Multi-GPU weight distribution (north_star: "RCCL broadcast of weights over xGMI"; the reference is single-process,
+ * inferencer.py:243-254).  The packed arena is position-independent and its layout depends on srh_model_cfg alone, so ONE
+ * rank packs a checkpoint and the others receive the packed fp16/f32 bytes device-to-device — no state_dict travels, no rank
+ * but the first reads the checkpoint or re-packs.  srh_weights_export: *bytes = size of the packed arena; with dst != NULL
+ * (device pointer, `capacity` bytes) the arena is copied there.  srh_weights_import: builds a weights object for `cfg` from
+ * such a copy (device pointer; SRH_ERR_BAD_ARG if `bytes` is not what `cfg` packs to). */
+int srh_weights_export(srh_ctx* ctx, const srh_weights* w, void* dst, size_t capacity, size_t* bytes);
+int srh_weights_import(srh_ctx* ctx, const srh_model_cfg* cfg, const void* src, size_t bytes, srh_weights** out);
 
 /* model ----------------------------------------------------------------------------------------- */
 
@@ -137,6 +151,10 @@ typedef struct {
 } srh_profile_row;
 int srh_profile_enable(srh_ctx* ctx, int on);
 int srh_profile_read(srh_ctx* ctx, srh_profile_row* rows, int max_rows, int* n_rows);
+/* Calibration of the above: the time an event pair adds around ONE launch — median over 32 launches of a kernel that spins
+ * for exactly 50 us of the 100 MHz wall clock, minus those 50 us — which a caller subtracts per launch to turn
+ * event-bracketed times into kernel durations (bench.py's roofline pass; checked against rocprofv3 in profiles/). */
+int srh_profile_overhead(srh_ctx* ctx, void* stream, double* ms_per_launch);
 
 /* ---- host-side geometry between the two GPU passes (no device work, callable without a GPU) ---------------
  * Greedy radius NMS of reference graph_utils.py:572-591 (nms_points), the step that turns the fused masks into

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRH_LIB_PATH") or os.path.join(_HERE, "libsamroad_hip.so")
 
 SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
+ABI_VERSION = 3
 
 
 class SrhError(RuntimeError):
@@ -37,11 +38,14 @@ class ProfileRow(C.Structure):
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SYMBOLS = {
     "srh_abi_version": (_I, []),
+    "srh_build_id": (C.c_char_p, []),
     "srh_ctx_create": (_I, [_I, C.POINTER(_P)]),
     "srh_ctx_destroy": (None, [_P]),
     "srh_last_error": (C.c_char_p, [_P]),
     "srh_weights_pack": (_I, [_P, C.POINTER(ModelCfg), C.POINTER(NamedTensor), _I, C.POINTER(_P)]),
     "srh_weights_free": (None, [_P]),
+    "srh_weights_export": (_I, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "srh_weights_import": (_I, [_P, C.POINTER(ModelCfg), _P, C.c_size_t, C.POINTER(_P)]),
     "srh_encode_decode": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "srh_toponet": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "srh_scene_pass1": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
@@ -60,9 +64,15 @@ SYMBOLS = {
     "srh_edge_vote_accumulate_mt": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32]),
     "srh_profile_enable": (_I, [_P, _I]),
     "srh_profile_read": (_I, [_P, C.POINTER(ProfileRow), _I, C.POINTER(_I)]),
+    "srh_profile_overhead": (_I, [_P, _P, C.POINTER(C.c_double)]),
 }
 
 _lib = None
+
+
+def build_id():
+    """Build id of the loaded library (sha256 of its sources, 16 hex digits; sam_road_amd/build.py source_id)."""
+    return load().srh_build_id().decode()
 
 
 def load():
@@ -78,7 +88,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.srh_abi_version() != 2:
+    if lib.srh_abi_version() != ABI_VERSION:
         raise SrhError("libsamroad_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -114,6 +124,12 @@ class Context:
 
     def profile_enable(self, on=True):
         self.check(self.lib.srh_profile_enable(self.handle, 1 if on else 0), "srh_profile_enable")
+
+    def profile_overhead(self, stream=None):
+        """ms an event pair adds around one launch (srh_profile_overhead)."""
+        v = C.c_double(0.0)
+        self.check(self.lib.srh_profile_overhead(self.handle, stream, C.byref(v)), "srh_profile_overhead")
+        return v.value
 
     def profile_read(self):
         rows = (ProfileRow * 64)()

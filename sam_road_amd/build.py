@@ -1,5 +1,6 @@
 """Build libsamroad_hip.so for gfx950 in-tree with hipcc (no torch extension machinery: the
 library is a plain C-ABI shared object, see include/samroad_hip.h)."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -19,24 +20,50 @@ def _hipcc():
     return "hipcc"
 
 
+_MARK = b"SRH_BUILD_ID="
+
+
+def source_id():
+    """sha256 over every file the library is built from (csrc/*, the public header, the flags), 16 hex digits.  It is compiled
+    into the library (srh_build_id()), so "is this .so the build of THESE sources" is a content check, not an mtime guess."""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "samroad_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS + SOURCES).encode())
+    return h.hexdigest()[:16]
+
+
+def library_id(path=LIB):
+    """The build id embedded in a built library (read from the file: no dlopen, so a stale library is never mapped)."""
+    try:
+        with open(path, "rb") as fh:
+            data = fh.read()
+    except OSError:
+        return None
+    i = data.find(_MARK)
+    return data[i + len(_MARK): i + len(_MARK) + 16].decode("ascii", "replace") if i >= 0 else None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "samroad_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_id() != source_id()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    sid = source_id()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + [f'-DSRH_BUILD_ID_HEX="{sid}"', "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -50,6 +77,8 @@ def build(force=False, verbose=True):
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    if library_id() != sid:
+        raise RuntimeError(f"built library carries build id {library_id()}, expected {sid}")
     return LIB
 
 

@@ -3,6 +3,7 @@
 // the scene-level pass 1 of infer_one_img.  Host-side C++ only; all arithmetic is in the .hip kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,7 +82,7 @@ struct srh_weights {
     srh_model_cfg cfg;
     SdW sd;
     int S = 0, D = 0, heads = 0, hd = 0;
-    void* arena = nullptr;
+    void* arena = nullptr; size_t arena_bytes = 0;
     f16* patch_w; float* patch_b; float* pos;
     std::vector<BlockW> blocks;
     f16 *neck0_w, *neck2_w; float *neck1_g, *neck1_b, *neck3_g, *neck3_b;
@@ -145,6 +146,14 @@ static int gemm(srh_ctx* c, const char* cls, const GemmParams& p_in, hipStream_t
 // ---- C ABI: lifetime -----------------------------------------------------------------------------
 extern "C" int srh_abi_version(void) { return SRH_ABI_VERSION; }
 
+#ifndef SRH_BUILD_ID_HEX
+#define SRH_BUILD_ID_HEX "unstamped-build!"
+#endif
+// sha256 of the sources this library was compiled from (sam_road_amd/build.py source_id); the marker is also what build.py
+// greps the file for
+static const char kBuildId[] = "SRH_BUILD_ID=" SRH_BUILD_ID_HEX;
+extern "C" const char* srh_build_id(void) { return kBuildId + 13; }
+
 extern "C" int srh_ctx_create(int device, srh_ctx** out) {
     if (!out) return SRH_ERR_BAD_ARG;
     *out = nullptr;
@@ -181,6 +190,7 @@ struct Packer {
     std::vector<std::pair<void**, size_t>> fix;   // pointer slots to patch with arena + offset
     std::vector<float> tmp;
     std::string missing;
+    bool layout_only = false;                     // srh_weights_import: only the arena layout is wanted, no tensor is read
 
     size_t alloc(size_t bytes) {
         const size_t off = (host.size() + 255) & ~size_t(255);
@@ -189,6 +199,7 @@ struct Packer {
     }
     // fetch tensor as host f32 (copying from device if needed); checks element count
     const float* get(const std::string& name, size_t expect) {
+        if (layout_only) return nullptr;
         auto it = by_name.find(name);
         if (it == by_name.end()) { if (missing.empty()) missing = name; return nullptr; }
         const srh_named_tensor* t = it->second;
@@ -406,9 +417,11 @@ static void pack_sam_decoder(Packer& pk, srh_weights* w) {
 }
 }  // namespace
 
-extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
-                                srh_weights** out) {
-    if (!c || !cfg || !tensors || !out) return fail(c, SRH_ERR_BAD_ARG, "srh_weights_pack: null argument");
+// arena_src == nullptr: pack from the state_dict entries.  Otherwise (srh_weights_import): the arena LAYOUT depends on cfg alone
+// (the same sequence of allocations), so the pointer table is rebuilt without reading a tensor and the packed bytes are copied
+// device-to-device from arena_src.
+static int pack_impl(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n, const void* arena_src,
+                     size_t arena_src_bytes, srh_weights** out) {
     *out = nullptr;
     const int D = cfg->embed_dim, heads = cfg->num_heads;
     if (D <= 0 || heads <= 0 || D % heads) return fail(c, SRH_ERR_BAD_ARG, "bad embed_dim / num_heads");
@@ -425,6 +438,7 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
     w->cfg = *cfg; w->S = S; w->D = D; w->heads = heads; w->hd = hd;
     Packer pk;
     pk.c = c;
+    pk.layout_only = arena_src != nullptr;
     for (int i = 0; i < n; ++i) pk.by_name[tensors[i].name] = &tensors[i];
     const std::string E = "image_encoder.";
 
@@ -514,13 +528,41 @@ extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_
         delete w;
         return fail(c, SRH_ERR_MISSING_WEIGHT, "state_dict entry missing or mis-shaped: " + pk.missing);
     }
+    if (arena_src && arena_src_bytes != pk.host.size()) {
+        delete w;
+        return fail(c, SRH_ERR_BAD_ARG, "srh_weights_import: the packed arena has " + std::to_string(arena_src_bytes) +
+                                        " bytes, this configuration packs to " + std::to_string(pk.host.size()));
+    }
     hipError_t e = hipMalloc(&w->arena, pk.host.size());
     if (e != hipSuccess) { delete w; return hip_fail(c, e, "hipMalloc(weights)"); }
-    e = hipMemcpy(w->arena, pk.host.data(), pk.host.size(), hipMemcpyHostToDevice);
+    w->arena_bytes = pk.host.size();
+    e = arena_src ? hipMemcpy(w->arena, arena_src, pk.host.size(), hipMemcpyDeviceToDevice)
+                  : hipMemcpy(w->arena, pk.host.data(), pk.host.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(w->arena); delete w; return hip_fail(c, e, "hipMemcpy(weights)"); }
     for (auto& f : pk.fix) *f.first = reinterpret_cast<char*>(w->arena) + f.second;
     *out = w;
     return SRH_OK;
+}
+
+extern "C" int srh_weights_pack(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tensor* tensors, int n,
+                                srh_weights** out) {
+    if (!c || !cfg || !tensors || !out) return fail(c, SRH_ERR_BAD_ARG, "srh_weights_pack: null argument");
+    return pack_impl(c, cfg, tensors, n, nullptr, 0, out);
+}
+
+extern "C" int srh_weights_export(srh_ctx* c, const srh_weights* w, void* dst, size_t capacity, size_t* bytes) {
+    if (!c || !w || !bytes) return fail(c, SRH_ERR_BAD_ARG, "srh_weights_export: null argument");
+    *bytes = w->arena_bytes;
+    if (!dst) return SRH_OK;
+    if (capacity < w->arena_bytes) return fail(c, SRH_ERR_BAD_ARG, "srh_weights_export: destination too small");
+    hipSetDevice(c->device);
+    const hipError_t e = hipMemcpy(dst, w->arena, w->arena_bytes, hipMemcpyDeviceToDevice);
+    return e == hipSuccess ? SRH_OK : hip_fail(c, e, "srh_weights_export");
+}
+
+extern "C" int srh_weights_import(srh_ctx* c, const srh_model_cfg* cfg, const void* src, size_t bytes, srh_weights** out) {
+    if (!c || !cfg || !src || !out) return fail(c, SRH_ERR_BAD_ARG, "srh_weights_import: null argument");
+    return pack_impl(c, cfg, nullptr, 0, src, bytes, out);
 }
 
 extern "C" void srh_weights_free(srh_weights* w) {
@@ -939,6 +981,38 @@ extern "C" int srh_profile_enable(srh_ctx* c, int on) {
     c->profiling = on != 0;
     c->prof.clear();
     c->ev_used = 0;
+    return 0;
+}
+
+// one wave that spins until the 100 MHz constant-rate clock has advanced by `ticks`: a kernel of KNOWN duration
+__global__ void srh_spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+}
+
+// What an event pair around ONE launch adds to the launch's own duration: median over 32 launches of (event-to-event time
+// around a kernel that runs for exactly 50 us) - 50 us, measured on `stream` with the device otherwise idle.
+extern "C" int srh_profile_overhead(srh_ctx* c, void* stream, double* ms_per_launch) {
+    if (!c || !ms_per_launch) return SRH_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int N = 32;
+    const unsigned long long ticks = 5000;                      // 50 us at the 100 MHz wall clock
+    std::vector<hipEvent_t> ev(2 * N);
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(c, SRH_ERR_HIP, "hipEventCreate failed");
+    for (int warm = 0; warm < 2; ++warm)
+        for (int i = 0; i < N; ++i) {
+            hipEventRecord(ev[2 * i], s);
+            hipLaunchKernelGGL(srh_spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+            hipEventRecord(ev[2 * i + 1], s);
+        }
+    hipError_t e = hipStreamSynchronize(s);
+    std::vector<float> d(N);
+    for (int i = 0; i < N; ++i) hipEventElapsedTime(&d[i], ev[2 * i], ev[2 * i + 1]);
+    for (auto& x : ev) hipEventDestroy(x);
+    if (e != hipSuccess) return hip_fail(c, e, "srh_profile_overhead");
+    std::sort(d.begin(), d.end());
+    *ms_per_launch = std::max(0.0, (double)d[N / 2] - 0.050);
     return 0;
 }
 

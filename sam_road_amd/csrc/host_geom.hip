@@ -17,7 +17,7 @@
 
 #include "../../include/samroad_hip.h"
 
-extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int32_t radius, uint8_t* kept) {
+extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int32_t radius, uint8_t* kept) try {
     if (n < 0 || radius < 0 || (n > 0 && (!xy || !force || !kept))) return SRH_ERR_BAD_ARG;
     if (n == 0) return 0;
     memset(kept, 1, (size_t)n);
@@ -62,7 +62,7 @@ extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int6
         kept[i] = 1;
     }
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // ---------------------------------------------------------------------------------------------------------------
 // Pass-2 query builder for ALL tiles of a scene in one call (reference inferencer.py:148-176, executed per tile from
@@ -82,7 +82,13 @@ extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int6
 #include <algorithm>
 #include <thread>
 
-extern "C" int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int64_t* counts) {
+// worker threads that are joined even when the scope is left by an exception (a std::system_error from a failed thread creation
+// would otherwise destroy joinable std::threads = std::terminate before the C-ABI catch block is reached)
+struct JoiningThreads : std::vector<std::thread> {
+    ~JoiningThreads() { for (auto& t : *this) if (t.joinable()) t.join(); }
+};
+
+extern "C" int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int64_t* counts) try {
     if (n < 0 || n_tiles < 0 || (n > 0 && !pts) || (n_tiles > 0 && (!boxes || !counts))) return SRH_ERR_BAD_ARG;
     for (int32_t t = 0; t < n_tiles; ++t) {
         const int64_t x0 = boxes[4 * t], y0 = boxes[4 * t + 1], x1 = boxes[4 * t + 2], y1 = boxes[4 * t + 3];
@@ -94,12 +100,12 @@ extern "C" int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* box
         counts[t] = c;
     }
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // offsets[t] = sum(counts[:t]) (caller);  ids [total];  knn [total, K] tile-local neighbour index or -1;
 // ambiguous [total]: per source point (1 = recompute this point with the reference's scipy call on its tile)
 extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
-                              const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads) {
+                              const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads) try {
     if (n < 0 || n_tiles < 0 || K <= 0 || radius < 0 || (n_tiles > 0 && (!boxes || !offsets || !ids || !knn || !ambiguous)))
         return SRH_ERR_BAD_ARG;
     const int64_t r2 = radius * radius;
@@ -158,7 +164,7 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     };
     const int32_t nt = std::max<int32_t>(1, std::min<int32_t>(n_threads, n_tiles));
     if (nt == 1) { work(0, n_tiles); return 0; }
-    std::vector<std::thread> pool;
+    JoiningThreads pool;
     const int32_t per = (n_tiles + nt - 1) / nt;
     for (int32_t w = 0; w < nt; ++w) {
         const int32_t b = w * per, e = std::min(n_tiles, b + per);
@@ -166,7 +172,7 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     }
     for (auto& th : pool) th.join();
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // ---------------------------------------------------------------------------------------------------------------
 // Directed edge votes (reference inferencer.py:209-221: a Python dict keyed by (src, tgt) accumulating score sums and
@@ -224,7 +230,7 @@ int64_t sort_accumulate_range(int64_t* kcur, uint32_t* idx, int64_t* ktmp, uint3
 // the same float64 sums, bit for bit, as with one thread.
 extern "C" int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
                                            double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique,
-                                           int32_t n_threads) {
+                                           int32_t n_threads) try {
     if (n < 0 || !n_unique || (n > 0 && (!keys || !scores || !out_keys || !out_sums || !out_counts))) return SRH_ERR_BAD_ARG;
     *n_unique = 0;
     if (n == 0) return 0;
@@ -251,7 +257,7 @@ extern "C" int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* sc
     std::vector<uint32_t> hist((size_t)T * NB, 0u);
     auto chunk = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
     {
-        std::vector<std::thread> pool;
+        JoiningThreads pool;
         for (int t = 0; t < T; ++t) pool.emplace_back([&, t] {
             uint32_t* h = hist.data() + (size_t)t * NB;
             const auto c = chunk(t);
@@ -279,7 +285,7 @@ extern "C" int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* sc
     std::vector<std::vector<int64_t>> ok((size_t)T), of((size_t)T);
     std::vector<std::vector<double>> os((size_t)T), oc((size_t)T);
     {
-        std::vector<std::thread> pool;
+        JoiningThreads pool;
         for (int t = 0; t < T; ++t) pool.emplace_back([&, t] {
             uint32_t* h = hist.data() + (size_t)t * NB;
             const auto c = chunk(t);
@@ -293,7 +299,7 @@ extern "C" int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* sc
         for (auto& th : pool) th.join();
     }
     {
-        std::vector<std::thread> pool;
+        JoiningThreads pool;
         for (int r = 0; r < T; ++r) pool.emplace_back([&, r] {
             const int64_t lo = bstart[(size_t)cut[(size_t)r]], hi = bstart[(size_t)cut[(size_t)r + 1]], m = hi - lo;
             if (m <= 0) return;
@@ -314,12 +320,12 @@ extern "C" int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* sc
     }
     *n_unique = u;
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys,
-                                        double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique) {
+                                        double* out_sums, double* out_counts, int64_t* out_first, int64_t* n_unique) try {
     return srh_edge_vote_accumulate_mt(keys, scores, n, out_keys, out_sums, out_counts, out_first, n_unique, 1);
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // ---------------------------------------------------------------------------------------------------------------
 // Directed edge votes of ONE TopoNet batch (reference inferencer.py:206-221: the triple Python loop over tiles, source
@@ -331,7 +337,7 @@ extern "C" int srh_edge_vote_accumulate(const int64_t* keys, const double* score
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, int32_t K, const int64_t* offsets,
                                const int64_t* ids, const int32_t* knn, int64_t n_points, int64_t* keys, double* votes,
-                               int64_t capacity, int64_t* count) {
+                               int64_t capacity, int64_t* count) try {
     if (!scores || !offsets || !ids || !knn || !keys || !votes || !count || nb < 0 || K <= 0) return SRH_ERR_BAD_ARG;
     int64_t c = *count;
     for (int32_t b = 0; b < nb; ++b) {
@@ -354,7 +360,7 @@ extern "C" int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, i
     }
     *count = c;
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // ---------------------------------------------------------------------------------------------------------------
 // Candidate pixels of a fused u8 mask (reference graph_extraction.py:24-28: `np.where(mask > threshold)` + the scores at
@@ -363,7 +369,7 @@ extern "C" int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, i
 // (THRESHOLD * 255): a u8 value v is a candidate iff (float)v > threshold.
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float threshold, int64_t* xy, uint8_t* scores,
-                                   int64_t capacity, int64_t* n) {
+                                   int64_t capacity, int64_t* n) try {
     if (!mask || !n || H < 0 || W < 0 || ((xy == nullptr) != (scores == nullptr))) return SRH_ERR_BAD_ARG;
     int first = 256;                      // smallest u8 value that passes
     for (int v = 255; v >= 0; --v) { if ((float)v > threshold) first = v; else break; }
@@ -395,7 +401,7 @@ extern "C" int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, fl
     }
     *n = c;
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // ---------------------------------------------------------------------------------------------------------------
 // Padded collate of one TopoNet batch (reference inferencer.py:179-185: graph_collate_fn-style zero padding of the per-tile
@@ -405,7 +411,7 @@ extern "C" int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, fl
 // [nb, n_max, K]; rows beyond a tile's count are zero.
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int srh_pass2_pack(const int64_t* offsets, const int64_t* local, const int32_t* knn, int32_t nb, int64_t n_max, int32_t K,
-                              float* points, int32_t* pairs, uint8_t* valid) {
+                              float* points, int32_t* pairs, uint8_t* valid) try {
     if (!offsets || !local || !knn || !points || !pairs || !valid || nb < 0 || n_max < 0 || K <= 0) return SRH_ERR_BAD_ARG;
     for (int32_t b = 0; b < nb; ++b) {
         const int64_t a = offsets[b], n = offsets[b + 1] - a;
@@ -429,4 +435,4 @@ extern "C" int srh_pass2_pack(const int64_t* offsets, const int64_t* local, cons
         std::memset(vl + n * K, 0, (size_t)(n_max - n) * K);
     }
     return 0;
-}
+} catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI

@@ -207,6 +207,7 @@ class SAMRoad(nn.Module):
         self.topo_net = _TopoNetParams(self._topo_version)
         self._packed = {}  # device index -> (Context, weights handle)
         self._packed_stamp = -1
+        self._stamp_tensors = None
         self._init_from_sam_checkpoint()
 
     # ---- init-time SAM checkpoint (model.py:365-411) ------------------------------------------------------
@@ -239,6 +240,7 @@ class SAMRoad(nn.Module):
         for ctx, handle in self._packed.values():
             ctx.lib.srh_weights_free(handle)
         self._packed = {}
+        self._stamp_tensors = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -262,7 +264,11 @@ class SAMRoad(nn.Module):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         # in-place parameter edits (p.data.copy_, an optimizer step, a manual LoRA merge, load_state_dict on a submodule) bump
         # the tensors' version counters: the packed fp16 copy is rebuilt instead of silently serving stale weights
-        stamp = sum(p._version for p in self.parameters())
+        # (buffers too — the prompt encoder's Gaussian matrix is baked into the packed SAM-decoder weights — and each tensor's
+        # storage address, so that `p.data = new_tensor` rebinding is seen as well)
+        if self._stamp_tensors is None:           # the module-tree walk costs more than the stamp: cached until _apply / load_state_dict
+            self._stamp_tensors = list(self.parameters()) + list(self.buffers())
+        stamp = hash(tuple((t._version, t.data_ptr()) for t in self._stamp_tensors))
         if stamp != self._packed_stamp:
             self._invalidate()
             self._packed_stamp = stamp

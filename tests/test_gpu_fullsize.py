@@ -3,6 +3,7 @@
     configs[1]  toponet_vitb_512_cityscale.yaml, B = 16 tiles of 512^2, ViT-B, all 12 blocks (the persistent q192 GEMMs)
     configs[2]  the same batch through SAMRoad.forward with 256 points / tile (sampler + TopoNet)
     configs[3]  toponet_vitb_512_cityscale_4x4.yaml: one 2048^2 scene, 16 tiles, INFER_BATCH_SIZE 16, infer_one_img
+                AND the shipped toponet_vitb_512_cityscale.yaml geometry: 256 tiles (16 x 16), INFER_BATCH_SIZE 64
     configs[4]  toponet_vith_256.yaml: ViT-H, 32 blocks, B = 8   (+ ViT-L, 24 blocks)
     stress      heavy-tailed weights (Student-t outlier channels) for the fp16 inter-kernel tensors
 
@@ -23,6 +24,8 @@ pytestmark = pytest.mark.gpu
 from oracle import scene as oscene
 from oracle.samroad import AttrDict, SAMRoadOracle
 from oracle.synth import synth_queries, synth_scene, synth_state_dict, synth_tiles
+
+import tolerances as T
 
 # the YAMLs' keys that matter on this path (config/toponet_vitb_512_cityscale.yaml, ..._4x4.yaml, toponet_vith_256.yaml)
 CITYSCALE = dict(DATASET="cityscale", NO_SAM=False, SAM_VERSION="vit_b", SAM_CKPT_PATH="", PATCH_SIZE=512, ENCODER_LORA=False,
@@ -69,15 +72,18 @@ def u8(t):
     return (t * 255).to(torch.uint8).int()
 
 
-def check_masks_emb(name, e, e_r, ms, ms_r, emb_rel=1e-2, emb_max=5e-2):
+def check_masks_emb(name, e, e_r, ms, ms_r):
     e, ms = e.float().cpu(), ms.float().cpu()
     r, m, sm = rel_l2(e, e_r), (e - e_r).abs().max().item(), (ms - ms_r).abs().max().item()
     lv = (u8(ms) - u8(ms_r)).abs()
-    within2 = (lv <= 2).float().mean().item()
-    _record(name, emb_rel_l2=r, emb_max_abs=m, mask_score_max_abs=sm, u8_within2=within2, u8_max=int(lv.max().item()))
+    within1 = (lv <= 1).float().mean().item()
+    _record(name, emb_rel_l2=r, emb_max_abs=m, mask_score_max_abs=sm, u8_within1=within1, u8_max=int(lv.max().item()))
     assert torch.isfinite(e).all() and torch.isfinite(ms).all()
-    assert r < emb_rel and m < emb_max, (r, m)
-    assert sm < 2e-2 and within2 >= 0.999, (sm, within2)
+    T.check(name + "_emb_rel_l2", r, T.EMB_REL_L2)
+    T.check(name + "_emb_max_abs", m, T.EMB_MAX_ABS)
+    T.check(name + "_mask_score", sm, T.MASK_SCORE)
+    assert int(lv.max().item()) <= 2
+    T.check(name + "_u8_within1", within1, T.U8_WITHIN1, at_least=True)
 
 
 @pytest.fixture(scope="module")
@@ -106,8 +112,9 @@ def test_configs1_and_2_b16_vitb512_vs_oracle(vitb512):
     _record("configs2_forward_b16_256pts", topo_score_max_abs=d.max().item(), topo_decisions_equal=agree,
             mask_logit_max_abs=dl, valid_pairs=int(v.sum().item()))
     assert torch.isfinite(ts[..., 0][v]).all()
-    assert d.max().item() < 2e-2 and agree >= 0.995
-    assert dl < 0.15                                        # logits are O(3..10): relative 1e-2
+    T.check("configs2_forward_b16_topo_score", d.max().item(), T.TOPO_SCORE)
+    T.check("configs2_forward_b16_topo_decisions", agree, T.TOPO_DECISIONS, at_least=True)
+    T.check("configs2_forward_b16_mask_logit", dl, T.MASK_LOGIT)                    # logits are O(3..10)
 
 
 def test_configs3_cityscale_4x4_scene_vs_oracle(vitb512):
@@ -141,7 +148,72 @@ def test_configs3_cityscale_4x4_scene_vs_oracle(vitb512):
             symmetric_difference=len(got ^ ref), mask_u8_max=int(max(dk.max(), dr.max())),
             mask_u8_within1=float(min((dk <= 1).mean(), (dr <= 1).mean())))
     assert {e for e in ref if e in firm} == {e for e in got if e in firm}
-    assert len(got ^ ref) <= max(2, 0.02 * len(ref))
+    assert len(got ^ ref) <= max(2, 0.006 * len(ref))       # measured 77 of 43 674 (all within 0.003 of the threshold)
+
+
+def test_configs3_cityscale_shipped_16x16_b64_scene_vs_oracle(vitb512):
+    """The geometry `ms/scene` is quoted on — the SHIPPED toponet_vitb_512_cityscale.yaml (:22-27): 16 x 16 = 256 overlapping tiles
+    of a 2048^2 scene (~30 tiles per pixel), SAMPLE_MARGIN 64, INFER_BATCH_SIZE 64 (65 536-row GEMMs) — against the oracle on all
+    256 tiles (reference inferencer.py:61-110 for pass 1, :120-234 for pass 2).  Stage-wise, like the 4x4 case: fused u8 masks,
+    per-tile embeddings of a sampled subset, points on identical masks, edges on identical points.  The oracle encodes the tiles
+    in chunks of 16 (a tile's result does not depend on its batch in eager fp32; 64 at once needs ~20 GB of attention
+    temporaries on the host); mask fusion and pass 2 use the YAML's batches of 64."""
+    from sam_road_amd import Config
+    from sam_road_amd.graph_points import extract_graph_points
+    from sam_road_amd.inferencer import infer_one_img
+    oracle, net = vitb512
+    cfg = dict(CITYSCALE)
+    assert cfg["INFER_PATCHES_PER_EDGE"] == 16 and cfg["INFER_BATCH_SIZE"] == 64 and cfg["SAMPLE_MARGIN"] == 64
+    img = synth_scene(2048, seed=12)
+    infos = oscene.get_patch_info_one_img(0, 2048, cfg["SAMPLE_MARGIN"], cfg["PATCH_SIZE"], cfg["INFER_PATCHES_PER_EDGE"])
+    assert len(infos) == 256
+    scores_r, feats16 = [], []
+    for i in range(0, 256, 16):
+        s_, f_ = oracle.infer_masks_and_img_features(oscene.get_batch_img_patches(img, infos[i:i + 16]))
+        scores_r.append(s_)
+        feats16.append(f_)
+    kp_r, road_r = oscene.fuse_masks(img.shape[:2], infos, scores_r)
+    # ---- HIP pass 1 at the YAML's batch size
+    xy = torch.tensor([[p_[1][0], p_[1][1]] for p_ in infos], dtype=torch.int32).cuda()
+    kp_c, road_c, emb = net.scene_pass1(torch.as_tensor(img).cuda(), xy, cfg["INFER_BATCH_SIZE"])
+    kp_t, road_t = net.scene_normalise(kp_c, road_c, xy)
+    kp, road = kp_t.cpu().numpy(), road_t.cpu().numpy()
+    dk, dr = np.abs(kp.astype(int) - kp_r.astype(int)), np.abs(road.astype(int) - road_r.astype(int))
+    assert dk.max() <= 2 and dr.max() <= 2
+    T.check("shipped16x16_mask_u8_within1", min((dk <= 1).mean(), (dr <= 1).mean()), T.U8_WITHIN1, at_least=True)
+    m = cfg["SAMPLE_MARGIN"]
+    assert (kp[:m] == 0).all() and (kp[:, :m] == 0).all() and (road[-m:] == 0).all() and (road[:, -m:] == 0).all()
+    # ---- per-tile embeddings: one tile of every 16-tile column of the grid + the four corners, against the oracle's
+    feats_all = torch.cat(feats16, 0)
+    sample = sorted(set(list(range(5, 256, 16)) + [0, 15, 240, 255]))
+    worst_rel, worst_abs = 0.0, 0.0
+    for t in sample:
+        e, e_r = emb[t].float().cpu(), feats_all[t]
+        worst_rel = max(worst_rel, rel_l2(e, e_r))
+        worst_abs = max(worst_abs, (e - e_r).abs().max().item())
+    T.check("shipped16x16_b64_emb_rel_l2", worst_rel, T.EMB_REL_L2)
+    T.check("shipped16x16_b64_emb_max_abs", worst_abs, T.EMB_MAX_ABS)
+    # ---- the whole pipeline (thresholds from the oracle masks: synthetic weights do not draw roads)
+    cfg["ITSC_THRESHOLD"] = float(np.percentile(kp_r[kp_r > 0], 99.7)) / 255.0
+    cfg["ROAD_THRESHOLD"] = float(np.percentile(road_r[road_r > 0], 98.5)) / 255.0
+    nodes, edges, kp2, road2 = infer_one_img(net, img, Config(cfg))
+    np.testing.assert_array_equal(kp2, kp)
+    np.testing.assert_array_equal(road2, road)
+    pts = extract_graph_points(kp, road, Config(cfg))
+    np.testing.assert_array_equal(pts, oscene.extract_graph_points(kp, road, AttrDict(cfg)))     # points on identical masks
+    np.testing.assert_array_equal(nodes, pts[:, ::-1])
+    assert pts.shape[0] > 1000
+    feats64 = [torch.cat(feats16[4 * i:4 * i + 4], 0) for i in range(4)]
+    edges_r, sums_r, cnts_r = oscene.infer_pass2(oracle, feats64, pts, infos, AttrDict(cfg))      # edges on identical points
+    got = {(int(a), int(b)) for a, b in edges.tolist()}
+    ref = {(int(a), int(b)) for a, b in edges_r.tolist()}
+    firm = {e_ for e_, s_ in sums_r.items() if abs(s_ / cnts_r[e_] - cfg["TOPO_THRESHOLD"]) > 0.003}
+    _record("configs3_cityscale_shipped_16x16_b64", points=int(pts.shape[0]), oracle_edges=len(ref), hip_edges=len(got),
+            symmetric_difference=len(got ^ ref), mask_u8_max=int(max(dk.max(), dr.max())),
+            mask_u8_within1=float(min((dk <= 1).mean(), (dr <= 1).mean())), emb_rel_l2_worst_of_sample=worst_rel,
+            emb_max_abs_worst_of_sample=worst_abs, sampled_tiles=len(sample))
+    assert {e_ for e_ in ref if e_ in firm} == {e_ for e_ in got if e_ in firm}
+    assert len(got ^ ref) <= max(2, 0.01 * len(ref))
 
 
 @pytest.mark.parametrize("name,cfg,B", [("configs4_vith256_b8_32blocks", VITH_256, 8), ("vitl256_b4_24blocks", VITL_256, 4)])
@@ -160,7 +232,7 @@ def test_configs4_vith_vitl_full_depth_vs_oracle(name, cfg, B):
     v = valid.bool()
     d = (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item()
     _record(name + "_topo", topo_score_max_abs=d)
-    assert d < 2e-2
+    T.check(name + "_topo_score", d, T.TOPO_SCORE)
 
 
 def _heavy_tails(scale):
@@ -184,4 +256,4 @@ def test_heavy_tailed_weights(scale):
     rgb = synth_tiles(4, 512, seed=2)
     ms_r, e_r = oracle.infer_masks_and_img_features(rgb)
     ms, e = net.infer_masks_and_img_features(rgb.cuda())
-    check_masks_emb(f"heavy_tailed_x{int(scale)}", e, e_r, ms, ms_r, emb_rel=2e-2, emb_max=1e-1)
+    check_masks_emb(f"heavy_tailed_x{int(scale)}", e, e_r, ms, ms_r)

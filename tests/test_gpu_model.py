@@ -1,10 +1,10 @@
 """Module-level parity of the HIP path (SAMRoad through the C ABI) against the CPU oracle on the same
 seeded synthetic state_dict and inputs.  Tolerances (fp16 MFMA operands, f32 accumulate, f32 residual
 stream vs the reference's eager fp32):
-    image embeddings   rel-L2 <= 1e-2, max-abs <= 5e-2  (post-LayerNorm2d values, O(1))
-    mask scores        max-abs <= 2e-2, u8 masks within +-2 levels on >= 99.9 % of pixels
-    topo scores        max-abs <= 2e-2 on valid pairs, edge decisions (>0.5) equal on >= 99.5 %
-Run on an MI355X: pytest -m gpu."""
+    image embeddings   rel-L2 <= 3e-3, max-abs <= 1.7e-2  (post-LayerNorm2d values, O(1))
+    mask scores        max-abs <= 5e-4, u8 masks within +-2 levels, +-1 on >= 99.9 % of pixels
+    topo scores        max-abs <= 3e-3 on valid pairs, edge decisions (>0.5) equal on >= 99.8 %
+— every bound is <= 3x the value measured on MI355X and lives in tests/tolerances.py.  Run on an MI355X: pytest -m gpu."""
 import warnings
 
 import numpy as np
@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 from oracle.samroad import AttrDict, SAMRoadOracle
 from oracle import scene as oscene
 from oracle.synth import synth_queries, synth_state_dict, synth_tiles, synth_scene
+
+import tolerances as T
 
 
 def build_pair(cfg_kwargs, seed=1234):
@@ -60,8 +62,9 @@ def test_shallow_encoder_parity(cfg, B, depth, gidx):
     e, s = e.cpu(), s.cpu()
     print("emb rel-l2", rel_l2(e, e_ref), "max", (e - e_ref).abs().max().item(),
           "score max", (s - s_ref).abs().max().item())
-    assert rel_l2(e, e_ref) < 5e-3
-    assert (s - s_ref).abs().max().item() < 1e-2
+    tag = f"shallow_{cfg['SAM_VERSION']}_{cfg['PATCH_SIZE']}_B{B}_d{depth}_g{len(gidx)}"
+    T.check(tag + "_emb_rel_l2", rel_l2(e, e_ref), T.EMB_REL_L2_SHALLOW)
+    T.check(tag + "_mask_score", (s - s_ref).abs().max().item(), T.MASK_SCORE)
 
 
 def test_full_forward_parity_vitb_512():
@@ -80,13 +83,17 @@ def test_full_forward_parity_vitb_512():
     print("emb rel-l2", rel_l2(e, e_r), "emb max", (e - e_r).abs().max().item())
     print("mask score max", (ms - ms_r).abs().max().item(), "logit max", (ml - ml_r).abs().max().item())
     print("topo score max", (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item())
-    assert rel_l2(e, e_r) < 1e-2 and (e - e_r).abs().max().item() < 5e-2
-    assert (ms - ms_r).abs().max().item() < 2e-2
+    T.check("forward_vitb512_b2_emb_rel_l2", rel_l2(e, e_r), T.EMB_REL_L2)
+    T.check("forward_vitb512_b2_emb_max_abs", (e - e_r).abs().max().item(), T.EMB_MAX_ABS)
+    T.check("forward_vitb512_b2_mask_score", (ms - ms_r).abs().max().item(), T.MASK_SCORE)
+    T.check("forward_vitb512_b2_mask_logit", (ml - ml_r).abs().max().item(), T.MASK_LOGIT)
     u8 = lambda t: (t * 255).to(torch.uint8).int()
-    assert ((u8(ms) - u8(ms_r)).abs() <= 2).float().mean().item() >= 0.999
-    assert (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item() < 2e-2
+    lv = (u8(ms) - u8(ms_r)).abs()
+    assert lv.max().item() <= 2
+    T.check("forward_vitb512_b2_u8_within1", (lv <= 1).float().mean().item(), T.U8_WITHIN1, at_least=True)
+    T.check("forward_vitb512_b2_topo_score", (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item(), T.TOPO_SCORE)
     agree = ((ts[..., 0][v] > 0.5) == (ts_r[..., 0][v] > 0.5)).float().mean().item()
-    assert agree >= 0.995
+    T.check("forward_vitb512_b2_topo_decisions", agree, T.TOPO_DECISIONS, at_least=True)
     assert torch.isfinite(ts[..., 0][v]).all()
 
 
@@ -98,8 +105,8 @@ def test_config1_256_tile():
     ml_r, ms_r, tl_r, ts_r = oracle(rgb, points, pairs, valid)
     ml, ms, tl, ts = [t.cpu() for t in net(rgb.cuda(), points.cuda(), pairs.cuda(), valid.cuda())]
     v = valid.bool()
-    assert (ms - ms_r).abs().max().item() < 2e-2
-    assert (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item() < 2e-2
+    T.check("config0_vitb256_b1_mask_score", (ms - ms_r).abs().max().item(), T.MASK_SCORE)
+    T.check("config0_vitb256_b1_topo_score", (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item(), T.TOPO_SCORE)
 
 
 def test_toponet_golden_through_hip(golden_dir):
@@ -119,7 +126,7 @@ def test_toponet_golden_through_hip(golden_dir):
     v = valid.numpy().astype(bool)
     err = np.abs(ts.numpy()[..., 0][v] - g["scores"][..., 0][v]).max()
     print("toponet vs reference-source golden: max abs", err)
-    assert err < 2e-2
+    T.check("toponet_normal_vs_reference_source_golden", err, T.TOPO_GOLDEN)
     # all-invalid row (flipped to all-valid) and out-of-tile points stay finite
     assert np.isfinite(ts.numpy()).all()
 
@@ -142,7 +149,8 @@ def test_toponet_variants_golden_through_hip(golden_dir, version):
     v = valid.numpy().astype(bool)
     err = np.abs(ts.numpy()[..., 0][v] - gv[version + "_scores"][..., 0][v]).max()
     print(version, "vs reference-source golden: max abs", err)
-    assert err < 2e-2 and np.isfinite(ts.numpy()).all()
+    T.check(f"toponet_{version}_vs_reference_source_golden", err, T.TOPO_GOLDEN)
+    assert np.isfinite(ts.numpy()).all()
 
 
 def test_u8_and_f32_inputs_agree():
@@ -168,8 +176,16 @@ def test_full_size_properties_baseline_config():
     sp, ep = net.infer_masks_and_img_features(rgb[perm].contiguous())
     assert torch.equal(sp, s0[perm]) and torch.equal(ep, e0[perm])
     s2, e2 = net.infer_masks_and_img_features(rgb[:2].contiguous())
-    assert rel_l2(e2.float().cpu(), e0[:2].float().cpu()) < 3e-3
-    assert (s2 - s0[:2]).abs().max().item() < 5e-3
+    # B = 32 and B = 64 (INFER_BATCH_SIZE of the shipped CityScale YAML: 65 536-row GEMMs): the first 16 tiles are the same tiles —
+    # every kernel on this path works per token row / per (tile, head, window), so the results must be BIT-identical
+    for Bbig in (32, 64):
+        big = torch.cat([rgb, synth_tiles(Bbig - 16, 512, seed=40 + Bbig).cuda()], 0)
+        sb, eb = net.infer_masks_and_img_features(big)
+        assert torch.isfinite(sb).all() and torch.isfinite(eb).all()
+        assert torch.equal(sb[:16], s0) and torch.equal(eb[:16], e0), f"B={Bbig} changes the result of a tile"
+        del big, sb, eb
+    T.check("batch16_vs_batch2_emb_rel_l2", rel_l2(e2.float().cpu(), e0[:2].float().cpu()), T.BATCH_INDEP_EMB_REL)
+    T.check("batch16_vs_batch2_mask_score", (s2 - s0[:2]).abs().max().item(), T.BATCH_INDEP_SCORE)
 
 
 @pytest.mark.parametrize("version", ["normal", "no_offset", "no_transformer"])
@@ -197,5 +213,4 @@ def test_toponet_ragged_and_variants(version):
     v[0, 3] = True          # flipped rows: every key takes part, every score is defined
     v[2, 36] = True
     err = (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item()
-    print(version, "max abs", err)
-    assert err < 1e-2
+    T.check(f"toponet_ragged_{version}_score", err, T.TOPO_SCORE)

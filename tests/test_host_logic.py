@@ -257,7 +257,10 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.srh_abi_version() == 2
+    assert lib.srh_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define SRH_ABI_VERSION (\d+)", header).group(1))
+    # the loaded library is the build of the sources in this tree (content hash compiled into it)
+    from sam_road_amd.build import library_id, source_id
+    assert _lib.build_id() == library_id() == source_id()
     # product package must not reference the oracle
     pkg = os.path.join(ROOT, "sam_road_amd")
     for fn in os.listdir(pkg):

@@ -2,7 +2,7 @@
 """Randomised HIP-vs-oracle parity sweep (run on an MI355X): random batch sizes (incl. 1 and odd ones that leave GEMM row tails),
 random point counts per tile (incl. 1, ragged, all-invalid rows), every TOPONET_VERSION, ViT-B 256 / 512 tiles at depth 2 and a
 small full infer_one_img with odd scene sizes / margins / batch sizes.  Prints one line per case and a summary; exit code 1 on any
-violation of the DESIGN §2 tolerances.   python tools/fuzz_parity.py [--cases 40] [--seed 0]"""
+violation of the stated tolerances (tests/tolerances.py).   python tools/fuzz_parity.py [--cases 40] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -13,6 +13,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import tolerances as T          # the stated tolerances (tests/tolerances.py)
 
 
 def main():
@@ -54,7 +56,8 @@ def main():
             P, sam = 256, str(rng.choice(["vit_l", "vit_h"]))
         cfg, oracle, net = pair(P, ver, gidx, sam)
         if c % 4 != 3 or sam != "vit_b":
-            B = int(rng.choice([1, 2, 3, 5, 7])) if P == 512 else int(rng.choice([1, 2, 3, 5, 9, 17]))
+            # up to the shipped YAMLs' INFER_BATCH_SIZE = 64 (and one past it): B >= 8 (512 px) / 32 (256 px) takes the persistent q192 GEMMs
+            B = int(rng.choice([1, 2, 3, 5, 7, 16, 32, 33])) if P == 512 else int(rng.choice([1, 2, 3, 5, 9, 17, 32, 64, 65]))
             npts = int(rng.choice([1, 2, 17, 40, 96]))
             rgb = synth_tiles(B, P, seed=int(rng.integers(1 << 30)))
             points, pairs, valid = synth_queries(B, npts, P, seed=int(rng.integers(1 << 30)))
@@ -65,7 +68,7 @@ def main():
             v = valid.bool()
             d_s = (ms - ms_r).abs().max().item()
             d_t = (ts[v] - ts_r[v]).abs().max().item() if v.any() else 0.0
-            ok = d_s < 2e-2 and d_t < 2e-2 and torch.isfinite(ml).all() and torch.isfinite(tl[v]).all()
+            ok = d_s < T.MASK_SCORE and d_t < T.TOPO_SCORE and torch.isfinite(ml).all() and torch.isfinite(tl[v]).all()
             print(f"case {c:3d} forward {sam} P={P} {ver:16s} global={gidx} B={B:2d} N={npts:3d}: mask {d_s:.1e} topo {d_t:.1e} {'ok' if ok else 'FAIL'}", flush=True)
         else:
             S = P + 2 * 16 + int(rng.integers(0, 5)) * 24

@@ -8,6 +8,7 @@ WORKLOAD=${2:-encdec}
 [ "$WORKLOAD" != encdec ] && TAG=${TAG}_${WORKLOAD}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
+python -c "import sys; sys.path.insert(0, '$R'); from sam_road_amd import _lib; print(_lib.build_id())" > $R/gpurun_out/${TAG}_build_id.txt
 cd /tmp
 BENCH="python $R/bench.py --workload $WORKLOAD --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-reference-gpu"
 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- $BENCH > $R/gpurun_out/${TAG}_prof.log 2>&1

@@ -46,8 +46,14 @@ def main():
     if tot_n:
         out["_gemm_all"] = {"launches_sampled": tot_n,
                             "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in gem) / tot_n}
+    # stamp the summary with the build it was measured on (tools/profile_gpu.sh wrote it on the GPU box): bench.py refuses a
+    # summary of another build instead of quoting stale traffic
+    bid_file = os.path.join(os.path.dirname(os.path.normpath(prof)), f"{tag}{sfx}_build_id.txt")
+    out["_build_id"] = open(bid_file).read().strip() if os.path.exists(bid_file) else None
     json.dump(out, open(f"profiles/{tag}_hbm_traffic{sfx}.json", "w"), indent=1)
     for k, v in out.items():
+        if not isinstance(v, dict):
+            continue
         print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch (n={v['launches_sampled']})")
 
 

@@ -73,7 +73,6 @@ def main():
 
     from sam_road_amd import Config, SAMRoad
     from sam_road_amd import _lib
-    from sam_road_amd.distributed import broadcast_state_dict
 
     WL = {"encdec": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE, yaml="toponet_vitb_512_cityscale.yaml",
                          what="ViT-B encoder + map_decoder (BASELINE configs[1])"),
@@ -97,10 +96,13 @@ def main():
         else:
             t = torch.empty(v.shape)
         sd[k] = t
-    if distributed:
-        sd = broadcast_state_dict(sd, src=0, device=dev)   # RCCL broadcast over xGMI
-    net.load_state_dict(sd, strict=True)
+    if rank == 0:
+        net.load_state_dict(sd, strict=True)
     net.eval().to(dev)
+    if distributed:
+        # rank 0 packs the weights once; the PACKED fp16 arena (~175 MB for ViT-B) goes to the other ranks device-to-device in
+        # one RCCL broadcast over xGMI (SAMRoad.share_packed_weights) — before the timed region
+        net.share_packed_weights(src=0)
 
     B = args.batch or WL["batch"]
     gi = torch.Generator().manual_seed(100 + rank)

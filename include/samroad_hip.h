@@ -152,7 +152,7 @@ typedef struct {
 int srh_profile_enable(srh_ctx* ctx, int on);
 int srh_profile_read(srh_ctx* ctx, srh_profile_row* rows, int max_rows, int* n_rows);
 /* Calibration of the above: the time an event pair adds around ONE launch — median over 32 launches of a kernel that spins
- * for exactly 50 us of the 100 MHz wall clock, minus those 50 us — which a caller subtracts per launch to turn
+ * for exactly 50 us of the 100 MHz wall clock, minus those 50 us and the kernel's own 1.5 us of ramp — which a caller subtracts per launch to turn
  * event-bracketed times into kernel durations (bench.py's roofline pass; checked against rocprofv3 in profiles/). */
 int srh_profile_overhead(srh_ctx* ctx, void* stream, double* ms_per_launch);
 
@@ -169,11 +169,21 @@ int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int3
  * (x0,y0,x1,y1), closed.  srh_pass2_count writes the number of points per tile; the caller builds
  * offsets = exclusive prefix sum and allocates ids [total] and knn [total,K]; srh_pass2_fill writes, per tile, the point
  * ids in ascending order and each point's K nearest other points of the tile (distance strictly < radius, ascending by
- * (distance, index); -1 = missing).  ambiguous [total]: 1 for a source point whose scipy result is not determined by
- * distances alone (tie at the cutoff, coincident points): the caller must recompute those points with scipy. */
+ * (distance, index); -1 = missing).  Where distances alone do not determine scipy's answer — the K-th and (K+1)-th neighbour
+ * equidistant, or a point coinciding with the source — the row is decided exactly as `scipy.spatial.KDTree(tile points)
+ * .query(p, k = K+1, distance_upper_bound = radius)[1:]` decides it (same kd-tree, traversal and heaps restated in
+ * csrc/kdtree_emul.hpp; scipy 1.15) and comes in scipy's output order; ambiguous [total] marks those rows (information
+ * only: nothing is left for the caller to recompute). */
 int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int64_t* counts);
 int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
                    const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads);
+
+/* `scipy.spatial.KDTree(points, leafsize).query(queries, k, distance_upper_bound=r)` (the reference's kNN, inferencer.py:156-160)
+ * restated for 2-D points, INCLUDING how scipy breaks ties between equidistant points: points f64 [n,2], queries f64 [nq,2] ->
+ * out_idx i32 [nq,k] in scipy's output order (n where fewer than k points lie within r); tree_indices (nullable) i32 [n]
+ * receives scipy's `tree.indices` permutation.  Host code; what srh_pass2_fill uses for tied cut-offs. */
+int srh_kdtree_knn_host(const double* points, int64_t n, int32_t leafsize, const double* queries, int64_t nq, int32_t k,
+                        double distance_upper_bound, int32_t* out_idx, int32_t* tree_indices);
 
 /* Candidate pixels of a fused u8 mask: reference graph_extraction.py:24-28 (`np.where(mask > threshold)` and the scores
  * there), row-major order.  Call with xy = scores = NULL to get *n, then again with xy int64 [n,2] (x, y) and scores u8 [n]

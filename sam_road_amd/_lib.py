@@ -59,6 +59,7 @@ SYMBOLS = {
     "srh_pass2_fill": (_I, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32]),
     "srh_pass2_votes": (_I, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),
     "srh_pass2_pack": (_I, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
+    "srh_kdtree_knn_host": (_I, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_double, _P, _P]),
     "srh_mask_candidates": (_I, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int64, _P]),
     "srh_edge_vote_accumulate": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "srh_edge_vote_accumulate_mt": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32]),

@@ -525,7 +525,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
 #ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): kernel / ablation selection by number
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
     const int variant = p.variant ? p.variant : env_variant;
-    if (variant >= 50 && variant <= 60) return launch_gemm_q192(p, stream, variant - 50);
+    if (variant >= 50 && variant <= 62) return launch_gemm_q192(p, stream, variant - 50);
 #else
     const int variant = 0;
 #endif

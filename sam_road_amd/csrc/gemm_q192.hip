@@ -172,6 +172,9 @@ void gemm_q192_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();                     // stagger: group 1 runs one segment behind group 0
 
+    // prio_mode 3 (probe): ONE static s_setprio 1 for the second-dispatched half (the arbitration loser on every segment,
+    // MI355X guide T5 static form) and no per-segment flips
+    if (p.prio_mode == 3 && g == 1) __builtin_amdgcn_s_setprio(1);
     f16x8 wf[3][2], xf[4][2];
     if (ABL == 5) {      // ablation: no fragment ds_reads (operands stay whatever the registers hold)
 #pragma unroll
@@ -190,7 +193,7 @@ void gemm_q192_kernel(GemmParams p) {
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) { asm volatile("" : "+v"(wf[nt][0])); asm volatile("" : "+v"(wf[nt][1])); } \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(xf[mt][0])); asm volatile("" : "+v"(xf[mt][1])); } \
     if (ABL != 2) { \
-    if (p.prio_mode == 0) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0); \
+    if (p.prio_mode == 0) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0); /* 1, 3: no flips */ \
     DMA \
     EPI \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
@@ -457,6 +460,12 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
     if (ablation == 8) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 2>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
     if (ablation == 9) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
     if (ablation == 10) { hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }
+    if (ablation == 11 || ablation == 12) {     // default schedules with prio_mode 3 (static young-half priority) / 1 (no s_setprio at all)
+        GemmParams q = p; q.prio_mode = ablation == 11 ? 3 : 1;
+        if (ACT == 1) hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 3>), dim3(grid), dim3(512), Q_LDS, stream, q);
+        else hipLaunchKernelGGL((gemm_q192_kernel<0, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, q);
+        return;
+    }
 #endif
     (void)ablation;
     // default: the GELU layer (fc1) takes the woven schedule (SCH 3: two epilogue VALU per MFMA gap; measured -3 % on fc1,

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/samroad_hip.h"
+#include "kdtree_emul.hpp"
 
 extern "C" int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int32_t radius, uint8_t* kept) try {
     if (n < 0 || radius < 0 || (n > 0 && (!xy || !force || !kept))) return SRH_ERR_BAD_ARG;
@@ -103,7 +104,9 @@ extern "C" int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* box
 } catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
 // offsets[t] = sum(counts[:t]) (caller);  ids [total];  knn [total, K] tile-local neighbour index or -1;
-// ambiguous [total]: per source point (1 = recompute this point with the reference's scipy call on its tile)
+// ambiguous [total]: per source point, 1 = its neighbours are not determined by distances alone (tie at the cut-off, a
+// coincident point) and were decided the way the reference's scipy.spatial.KDTree(tile points).query decides them
+// (kdtree_emul.hpp: the same tree, the same traversal, the same heaps), in scipy's output order
 extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
                               const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads) try {
     if (n < 0 || n_tiles < 0 || K <= 0 || radius < 0 || (n_tiles > 0 && (!boxes || !offsets || !ids || !knn || !ambiguous)))
@@ -112,8 +115,12 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     auto work = [&](int32_t t_begin, int32_t t_end) {
         std::vector<int64_t> lx, ly;
         std::vector<std::pair<int64_t, int32_t>> cand;
-        std::vector<int32_t> cstart, cfill, pcell, corder;
+        std::vector<int32_t> cstart, cfill, pcell, corder, res;
+        std::vector<double> local;
+        std::vector<srh_kd::detail::NodeInfo> pool;
+        srh_kd::Tree tree;
         for (int32_t t = t_begin; t < t_end; ++t) {
+            bool any_amb = false;
             const int64_t x0 = boxes[4 * t], y0 = boxes[4 * t + 1], x1 = boxes[4 * t + 2], y1 = boxes[4 * t + 3];
             int64_t* tid = ids + offsets[t];
             int32_t* tk = knn + offsets[t] * K;
@@ -159,6 +166,20 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
                 amb |= !cand.empty() && cand[0].first == 0;             // a point coinciding with the source
                 for (size_t q = 0; q < (size_t)K; ++q) tk[(size_t)i * K + q] = q < keep ? cand[q].second : -1;
                 tamb[i] = amb ? 1 : 0;
+                any_amb |= amb;
+            }
+            if (any_amb) {
+                // the reference's own query for those points: KDTree(tile-local points, ids ascending).query(p, k = K + 1,
+                // distance_upper_bound = radius)[:, 1:] (reference inferencer.py:156-160)
+                local.resize((size_t)m * 2);
+                for (int32_t i = 0; i < m; ++i) { local[(size_t)i * 2] = (double)(lx[i] - x0); local[(size_t)i * 2 + 1] = (double)(ly[i] - y0); }
+                srh_kd::build(tree, local.data(), m, 10);
+                res.resize((size_t)K + 1);
+                for (int32_t i = 0; i < m; ++i) {
+                    if (!tamb[i]) continue;
+                    srh_kd::query(tree, &local[(size_t)i * 2], K + 1, (double)radius, res.data(), nullptr, pool);
+                    for (int32_t q = 0; q < K; ++q) tk[(size_t)i * K + q] = res[(size_t)q + 1] < m ? res[(size_t)q + 1] : -1;
+                }
             }
         }
     };
@@ -173,6 +194,21 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     for (auto& th : pool) th.join();
     return 0;
 } catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
+
+// scipy.spatial.KDTree(points[n,2], leafsize).query(queries[nq,2], k, distance_upper_bound) restated (kdtree_emul.hpp): out_idx
+// [nq,k] in scipy's output order (n = missing), tree_indices [n] (nullable) = scipy's tree.indices.  What srh_pass2_fill uses for
+// tied cut-offs; exported so that the parity tests can pin tree structure and query results against scipy directly.
+extern "C" int srh_kdtree_knn_host(const double* points, int64_t n, int32_t leafsize, const double* queries, int64_t nq, int32_t k,
+                                   double distance_upper_bound, int32_t* out_idx, int32_t* tree_indices) try {
+    if (n < 0 || nq < 0 || k <= 0 || leafsize <= 0 || n > 0x7fffffff || (n > 0 && !points) || (nq > 0 && (!queries || !out_idx)))
+        return SRH_ERR_BAD_ARG;
+    srh_kd::Tree tree;
+    srh_kd::build(tree, points, (int32_t)n, leafsize);
+    if (tree_indices) std::copy(tree.idx.begin(), tree.idx.end(), tree_indices);
+    std::vector<srh_kd::detail::NodeInfo> pool;
+    for (int64_t i = 0; i < nq; ++i) srh_kd::query(tree, queries + 2 * i, k, distance_upper_bound, out_idx + i * k, nullptr, pool);
+    return 0;
+} catch (...) { return SRH_ERR_HIP; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Directed edge votes (reference inferencer.py:209-221: a Python dict keyed by (src, tgt) accumulating score sums and

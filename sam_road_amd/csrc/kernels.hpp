@@ -16,7 +16,7 @@ struct GemmParams {
     int act = 0;                               // 0 none, 1 exact-erf GELU, 2 ReLU (applied after bias)
     int conv_S = 0, conv_C = 0;                // >0: implicit 3x3 conv over [B,S,S,C]
     int tile_gr = 0;                           // tuning aid (env SRH_Q192_GR): tile rows per XCD-local group, 0 = default 4
-    int prio_mode = 0;                         // tuning aid (env SRH_Q192_PRIO): 0 s_setprio 1 around the MFMA segment, 1 none, 2 around the read segment
+    int prio_mode = 0;                         // tuning aid (env SRH_Q192_PRIO): 0 s_setprio 1 around the MFMA segment, 1 none, 2 around the read segment, 3 one static s_setprio 1 for waves 4-7
     unsigned long long* dbg = nullptr;         // tuning aid (gemm_q192 ablation 3): per-segment cycle sums
     int variant = 0;                           // 0 LDS-DMA 128x128 (default), 1 register-staged 128x128, 2 register-staged 256x256
     // split-K for layers with too few 128x128 tiles to fill the chip (small M: ViT-L / ViT-H at 256 px): splitk workgroups

@@ -45,8 +45,9 @@ class _FlatQueries:
     """Pass-2 queries of tiles [lo, hi) as flat arrays (the library's layout): offsets [n_tiles+1] rows per tile, ids [total]
     global point index of every row, local [total,2] tile-local (x, y), knn [total,K] int32 tile-local target or -1."""
 
-    def __init__(self, offsets, ids, local, knn):
+    def __init__(self, offsets, ids, local, knn, tied=None):
         self.offsets, self.ids, self.local, self.knn = offsets, ids, local, knn
+        self.tied = tied          # u8 [total]: rows decided by the kd-tree restatement (tie at the cut-off / coincident point)
         self.n_tiles = offsets.shape[0] - 1
 
     def tile(self, t):
@@ -62,9 +63,10 @@ class _FlatQueries:
 def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     """build_patch_queries for tiles [lo, hi) in ONE call into the library's host code (srh_pass2_count / srh_pass2_fill,
     csrc/host_geom.hip: closed-box filter + exact integer kNN per tile, worker threads).  Source points whose scipy result is
-    not determined by distances alone (tie at the k-th neighbour, coincident points) are recomputed with the reference's own
-    scipy call on a kd-tree of their tile's points (ids ascending), so the neighbour SETS equal those of the reference's call;
-    the order inside a group of equidistant neighbours is scipy-internal.  Returns a list of per-tile tuples, or the flat form."""
+    not determined by distances alone (tie at the k-th neighbour, coincident points) are answered by the library's restatement
+    of scipy's kd-tree on their tile's points (ids ascending; csrc/kdtree_emul.hpp), so those rows equal the reference's call
+    element for element; elsewhere the order inside a group of equidistant neighbours is (distance, index) where scipy's is
+    heap-internal.  Returns a list of per-tile tuples, or the flat form."""
     import ctypes as C
     import os
     from . import _lib
@@ -103,22 +105,10 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     tile_of = np.repeat(np.arange(n_tiles), counts)
     local = pts[ids] - boxes[tile_of, :2].astype(np.int64)
     lap("numpy post")
-    # ambiguous source points: the reference's own scipy query, on a kd-tree of their tile's points (rows overwritten in place)
-    amb_rows = np.nonzero(amb)[0]
-    if amb_rows.size:
-        # scipy.spatial.KDTree(pts) IS cKDTree(pts, leafsize=10, compact_nodes=True, balanced_tree=True) behind a Python
-        # wrapper (scipy/spatial/_kdtree.py); the C class is used directly here (same tree, same answers — pinned against the
-        # reference's own call by tests/test_host_logic.py) because ~150 tiles per scene need one.  Serial on purpose: the
-        # per-tile work is mostly interpreter time, a thread pool made it 3x slower.
-        for t in np.unique(tile_of[amb_rows]):
-            a, b_ = int(offsets[t]), int(offsets[t + 1])
-            rows = amb_rows[np.searchsorted(amb_rows, a):np.searchsorted(amb_rows, b_)]
-            tree = scipy.spatial.cKDTree(local[a:b_], leafsize=10)
-            _, nn = tree.query(local[rows], k=k + 1, distance_upper_bound=r)
-            nn = nn[:, 1:]
-            knn[rows] = np.where(nn < (b_ - a), nn, -1)
-    lap("tied re-queries")
-    fq = _FlatQueries(offsets, ids, local, knn)
+    # (source points whose answer is not determined by distances alone — a tie at the K-th neighbour, a coincident point — were
+    # decided inside the library the way the reference's scipy kd-tree decides them, csrc/kdtree_emul.hpp; round 2 re-queried
+    # scipy per tile here: 11.5 ms per CityScale scene)
+    fq = _FlatQueries(offsets, ids, local, knn, amb)
     if flat:
         return fq
     return [fq.tile(t) for t in range(n_tiles)]
@@ -213,10 +203,12 @@ def _accumulate_votes(k, s):
     return uk[:nu.value], sums[:nu.value], cnts[:nu.value], first[:nu.value]
 
 
-def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
+def edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=False):
     """Pass 2 over tiles [lo, hi) whose embeddings are emb[0 : hi-lo] (inferencer.py:135-221): returns the
     unique directed edge keys (src * n_points + tgt) with their score sums, counts and first-vote positions.  The sums are
-    accumulated in float64 in the reference's order (tile, point, neighbour slot), so they are bit-identical to its dict loop."""
+    accumulated in float64 in the reference's order (tile, point, neighbour slot), so they are bit-identical to its dict loop
+    for the tiles of THIS call (a multi-rank merge of such results: see distributed.gather_edge_votes).  raw=True returns the
+    votes themselves, (keys int64, scores float64) in visiting order, for an exact merge on one rank."""
     import os
     import time
     prof = os.environ.get("SRH_PROFILE_HOST") == "1"      # tuning aid: print the wall time of each section
@@ -228,7 +220,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
     bs = int(config.INFER_BATCH_SIZE)
     n_pts = graph_points.shape[0]
     K = int(config.MAX_NEIGHBOR_QUERIES)
-    empty = (np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0, np.int64))
+    empty = (np.zeros(0, np.int64), np.zeros(0)) if raw else (np.zeros(0, np.int64), np.zeros(0), np.zeros(0), np.zeros(0, np.int64))
     fq = build_all_patch_queries(graph_points, infos, lo, hi, config, flat=True)
     lap("build_all_patch_queries")
     if fq is None:
@@ -278,6 +270,8 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device):
         k = np.ascontiguousarray(np.concatenate(keys_l), dtype=np.int64)
         s = np.ascontiguousarray(np.concatenate(score_l), dtype=np.float64)
     lap("score fetch + keys")
+    if raw:
+        return k, s
     if k.shape[0] == 0:
         return empty
     out = _accumulate_votes(k, s)
@@ -385,7 +379,7 @@ def _infer_one_img(net, img, config, device=None):
     lap("scene upload")
     kp_c, road_c, emb = net.scene_pass1(scene, xy_dev[lo:hi], bs)      # an empty shard (world > n_tiles) returns zero canvases
     lap("pass 1 (GPU)")
-    D.reduce_canvases(kp_c, road_c, dst=0)
+    D.reduce_canvases(kp_c, road_c, dst=0, bands=D.tile_bands(all_xy, int(config.PATCH_SIZE), world) if world > 1 else None)
     graph_points = None
     kp_mask = road_mask = None
     if rank == 0:
@@ -402,10 +396,18 @@ def _infer_one_img(net, img, config, device=None):
 
     # ---- pass 2: per-tile queries (host) -> sampler + TopoNet (GPU) -> directed edge votes
     n_pts = graph_points.shape[0]
-    uk, sums, cnts, first = edge_votes(net, emb, graph_points, infos, lo, hi, config, device)
-    lap("edge_votes")
-    uk, sums, cnts, first = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None,
-                                                first=first)
+    if world > 1 and config.EXACT_VOTE_MERGE:
+        # exact multi-rank merge (extension key, default off): every raw vote goes to rank 0 in the one-process visiting order
+        k_raw, s_raw = edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=True)
+        k_raw, s_raw = D.gather_raw_votes(k_raw, s_raw, dst=0, device=device)
+        if rank != 0:
+            return None
+        uk, sums, cnts, first = _accumulate_votes(k_raw, s_raw)
+    else:
+        uk, sums, cnts, first = edge_votes(net, emb, graph_points, infos, lo, hi, config, device)
+        lap("edge_votes")
+        uk, sums, cnts, first = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None,
+                                                    first=first)
     if rank != 0:
         return None
     pred_edges = votes_to_edges(uk, sums, cnts, first, n_pts, config.TOPO_THRESHOLD)
@@ -648,14 +650,19 @@ def create_output_dir_and_save_config(output_dir_prefix, config, specified_dir=N
 
 
 def _build_net(config, checkpoint, device):
-    """inferencer.py:246-254."""
+    """inferencer.py:246-254.  Under torchrun only rank 0 reads the checkpoint: it packs the weights once and the packed arena
+    is broadcast device-to-device over RCCL (SAMRoad.share_packed_weights); the other ranks never touch the file."""
     from .model import SAMRoad
     net = SAMRoad(config)
-    ckpt = torch.load(checkpoint, map_location="cpu")
-    print(f"##### Loading Trained CKPT {checkpoint} #####")
-    net.load_state_dict(ckpt["state_dict"], strict=True)
+    shared = D.is_distributed() and device.type == "cuda"
+    if not shared or torch.distributed.get_rank() == 0:
+        ckpt = torch.load(checkpoint, map_location="cpu")
+        print(f"##### Loading Trained CKPT {checkpoint} #####")
+        net.load_state_dict(ckpt["state_dict"], strict=True)
     net.eval()
     net.to(device)
+    if shared:
+        net.share_packed_weights(src=0)
     return net
 
 

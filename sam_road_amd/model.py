@@ -208,6 +208,7 @@ class SAMRoad(nn.Module):
         self._packed = {}  # device index -> (Context, weights handle)
         self._packed_stamp = -1
         self._stamp_tensors = None
+        self._imported = False                    # True: the packed weights came from another rank (import_packed)
         self._init_from_sam_checkpoint()
 
     # ---- init-time SAM checkpoint (model.py:365-411) ------------------------------------------------------
@@ -245,6 +246,7 @@ class SAMRoad(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self._invalidate()
+        self._imported = False
         return out
 
     def _apply(self, fn, *args, **kwargs):
@@ -258,6 +260,68 @@ class SAMRoad(nn.Module):
         except Exception:
             pass
 
+    def _model_cfg(self):
+        """The architecture record the library packs / lays out weights for (include/samroad_hip.h srh_model_cfg)."""
+        cfg = _lib.ModelCfg()
+        cfg.embed_dim, cfg.depth, cfg.num_heads = self.arch["embed_dim"], self.arch["depth"], self.arch["num_heads"]
+        cfg.patch_size = int(self.config.PATCH_SIZE)
+        gi = list(self.arch["global_attn_indexes"])
+        cfg.n_global = len(gi)
+        for i, g in enumerate(gi):
+            cfg.global_attn_indexes[i] = g
+        cfg.window_size = 14
+        cfg.toponet_version = {"no_offset": 1, "no_transformer": 2}.get(self._topo_version, 0)
+        cfg.use_sam_decoder = 1 if self.config.USE_SAM_DECODER else 0
+        return cfg
+
+    def _stamp(self):
+        if self._stamp_tensors is None:           # the module-tree walk costs more than the stamp: cached until _apply / load_state_dict
+            self._stamp_tensors = list(self.parameters()) + list(self.buffers())
+        return hash(tuple((t._version, t.data_ptr()) for t in self._stamp_tensors))
+
+    # ---- multi-GPU: the PACKED weights travel, not the state_dict (north_star: "RCCL broadcast of weights over xGMI") -------
+    def export_packed(self, device):
+        """The packed weight arena of this model on `device` (fp16 MFMA operands, f32 biases / LayerNorm / pos-embed, packed
+        TopoNet fragments — what srh_weights_pack built) as a uint8 tensor on that device."""
+        ctx, wh = self._weights(torch.device(device))
+        n = C.c_size_t(0)
+        ctx.check(ctx.lib.srh_weights_export(ctx.handle, wh, None, 0, C.byref(n)), "srh_weights_export")
+        buf = torch.empty(n.value, dtype=torch.uint8, device=device)
+        ctx.check(ctx.lib.srh_weights_export(ctx.handle, wh, buf.data_ptr(), n.value, C.byref(n)), "srh_weights_export")
+        return buf
+
+    def import_packed(self, buf):
+        """Adopt packed weights produced by export_packed of a model with the SAME configuration (on another rank).  From here on
+        this model's Python parameters are NOT what it computes with; editing them raises instead of silently re-packing."""
+        dev = buf.device
+        if dev.type != "cuda" or buf.dtype != torch.uint8:
+            raise _lib.SrhError("import_packed expects a uint8 tensor on an MI355X")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ctx = _lib.Context.get(idx)
+        self._invalidate()
+        cfg = self._model_cfg()
+        handle = C.c_void_p()
+        with torch.cuda.device(dev):
+            ctx.check(ctx.lib.srh_weights_import(ctx.handle, C.byref(cfg), buf.data_ptr(), buf.numel(), C.byref(handle)),
+                      "srh_weights_import")
+        self._packed[idx] = (ctx, handle)
+        self._packed_stamp = self._stamp()
+        self._imported = True
+
+    def share_packed_weights(self, src=0):
+        """torch.distributed (backend nccl = RCCL over xGMI): rank `src` packs its checkpoint once and broadcasts the packed
+        arena device-to-device (one large collective: ~175 MB for ViT-B instead of 360 MB of f32 state_dict plus a host re-pack
+        on every rank); the other ranks never read the checkpoint.  No-op without an initialised process group."""
+        from . import distributed as D
+        if not D.is_distributed():
+            return
+        dev = next(self.parameters()).device
+        rank = torch.distributed.get_rank()
+        buf = self.export_packed(dev) if rank == src else None
+        buf = D.broadcast_bytes(buf, src=src, device=dev)
+        if rank != src:
+            self.import_packed(buf)
+
     def _weights(self, device):
         if device.type != "cuda":
             raise _lib.SrhError("SAMRoad runs on an MI355X only (tensor is on %s); there is no CPU fallback" % device)
@@ -266,10 +330,11 @@ class SAMRoad(nn.Module):
         # the tensors' version counters: the packed fp16 copy is rebuilt instead of silently serving stale weights
         # (buffers too — the prompt encoder's Gaussian matrix is baked into the packed SAM-decoder weights — and each tensor's
         # storage address, so that `p.data = new_tensor` rebinding is seen as well)
-        if self._stamp_tensors is None:           # the module-tree walk costs more than the stamp: cached until _apply / load_state_dict
-            self._stamp_tensors = list(self.parameters()) + list(self.buffers())
-        stamp = hash(tuple((t._version, t.data_ptr()) for t in self._stamp_tensors))
+        stamp = self._stamp()
         if stamp != self._packed_stamp:
+            if self._imported:
+                raise _lib.SrhError("this model computes with packed weights imported from another rank (share_packed_weights); "
+                                    "its parameters were edited or moved afterwards — re-share the weights instead")
             self._invalidate()
             self._packed_stamp = stamp
         hit = self._packed.get(idx)
@@ -285,16 +350,7 @@ class SAMRoad(nn.Module):
             w[:d] += sd[base + "linear_b_q.weight"] @ sd[base + "linear_a_q.weight"]
             w[2 * d:] += sd[base + "linear_b_v.weight"] @ sd[base + "linear_a_v.weight"]
             sd[base + "weight"] = w
-        cfg = _lib.ModelCfg()
-        cfg.embed_dim, cfg.depth, cfg.num_heads = self.arch["embed_dim"], self.arch["depth"], self.arch["num_heads"]
-        cfg.patch_size = int(self.config.PATCH_SIZE)
-        gi = list(self.arch["global_attn_indexes"])
-        cfg.n_global = len(gi)
-        for i, g in enumerate(gi):
-            cfg.global_attn_indexes[i] = g
-        cfg.window_size = 14
-        cfg.toponet_version = {"no_offset": 1, "no_transformer": 2}.get(self._topo_version, 0)
-        cfg.use_sam_decoder = 1 if self.config.USE_SAM_DECODER else 0
+        cfg = self._model_cfg()
         names = [k for k in sd if ".linear_" not in k]
         arr = (_lib.NamedTensor * len(names))()
         keep = []

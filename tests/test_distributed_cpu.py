@@ -41,10 +41,36 @@ def _worker(rank, world, port, out):
         kp = torch.zeros((S, S)); rd = torch.zeros((S, S))
         for (x, y), pch in zip(tiles[lo:hi], patches[lo:hi]):
             kp[y:y + P, x:x + P] += torch.tensor(pch[..., 0]); rd[y:y + P, x:x + P] += torch.tensor(pch[..., 1])
-        D.reduce_canvases(kp, rd, dst=0)
+        kp_dense, rd_dense = kp.clone(), rd.clone()
+        D.reduce_canvases(kp_dense, rd_dense, dst=0)                     # dense form: one reduce of both full canvases
+        # band form: every rank ships only the columns its tile chunk touches (x-outer tile order => vertical bands)
+        bands = D.tile_bands(np.array(tiles), P, world)
+        assert bands == [(0, 21 + P), (43, 64 + P)] if world == 2 else True
+        for r_, (x0, x1) in enumerate(bands):                            # a rank's canvas is zero outside its band
+            if r_ == rank:
+                assert float(kp[:, :x0].abs().sum() + kp[:, x1:].abs().sum()) == 0.0
+        D.reduce_canvases(kp, rd, dst=0, bands=bands)
         if rank == 0:
             np.testing.assert_allclose(kp.numpy(), full_kp, atol=1e-5)
             np.testing.assert_allclose(rd.numpy(), full_rd, atol=1e-5)
+            np.testing.assert_allclose(kp_dense.numpy(), full_kp, atol=1e-5)
+            assert torch.equal(kp, kp_dense) and torch.equal(rd, rd_dense)   # two ranks: one addition per pixel either way
+        # packed weights: a byte buffer held by rank 0 only
+        blob = torch.arange(1000, dtype=torch.int64).to(torch.uint8) if rank == 0 else None
+        got_blob = D.broadcast_bytes(blob, src=0)
+        assert got_blob.dtype == torch.uint8 and torch.equal(got_blob, torch.arange(1000, dtype=torch.int64).to(torch.uint8))
+        # raw votes: rank-major concatenation == the one-process visiting order, so ONE accumulation is exact
+        rngv = np.random.default_rng(5)
+        all_k = rngv.integers(0, 50, size=400).astype(np.int64)
+        all_s = rngv.random(400)
+        cut = 170
+        kk, ss = (all_k[:cut], all_s[:cut]) if rank == 0 else (all_k[cut:], all_s[cut:])
+        gk, gs = D.gather_raw_votes(kk, ss, dst=0)
+        if rank == 0:
+            np.testing.assert_array_equal(gk, all_k)
+            np.testing.assert_array_equal(gs, all_s)
+        else:
+            assert gk is None and gs is None
         # points broadcast (incl. empty)
         pts = np.array([[3, 4], [50, 60], [7, 7]], dtype=np.int64)
         np.testing.assert_array_equal(D.broadcast_points(pts if rank == 0 else None, src=0), pts)
@@ -167,6 +193,7 @@ import pytest
 @pytest.mark.parametrize("scene_size,overrides,must_be_identical", [
     (_E2E_SCENE, None, False),                                               # overlapping tiles (the shipped tilings)
     (512, dict(SAMPLE_MARGIN=0, INFER_PATCHES_PER_EDGE=2), True),            # disjoint tiles: every canvas pixel has ONE addend
+    (512, dict(SAMPLE_MARGIN=0, INFER_PATCHES_PER_EDGE=2, EXACT_VOTE_MERGE=True), True),   # raw votes merged on rank 0 (exact sums)
 ])
 def test_infer_one_img_world3_matches_single_process(scene_size, overrides, must_be_identical):
     ctx = mp.get_context("spawn")

@@ -214,3 +214,33 @@ def test_toponet_ragged_and_variants(version):
     v[2, 36] = True
     err = (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item()
     T.check(f"toponet_ragged_{version}_score", err, T.TOPO_SCORE)
+
+
+def test_packed_weights_export_import_roundtrip():
+    """The multi-GPU weight path on one GPU (SAMRoad.share_packed_weights = export on rank 0, RCCL broadcast, import elsewhere):
+    a second model of the same configuration with DIFFERENT parameters adopts the exported packed arena and must reproduce the
+    first model's outputs bit for bit, TopoNet included; a mismatching configuration is refused; editing the parameters of a
+    model that runs on imported weights raises instead of silently re-packing the local ones."""
+    from sam_road_amd import Config, SAMRoad, _lib
+    cfg = CFG256 | dict(ENCODER_DEPTH=2, ENCODER_GLOBAL_ATTN_INDEXES=[1])
+    _, net = build_pair(cfg)
+    rgb = synth_tiles(2, 256, seed=8).cuda()
+    points, pairs, valid = (t.cuda() for t in synth_queries(2, 40, 256, seed=4))
+    want = net(rgb, points, pairs, valid)
+    buf = net.export_packed(torch.device("cuda", 0))
+    assert buf.dtype == torch.uint8 and buf.is_cuda and buf.numel() > 1 << 20
+    other = SAMRoad(Config(cfg))                      # its own (default-initialised) parameters
+    other.eval().to("cuda")
+    assert not torch.equal(other(rgb, points, pairs, valid)[1], want[1])
+    other.import_packed(buf.clone())
+    got = other(rgb, points, pairs, valid)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    wrong = SAMRoad(Config(cfg | dict(ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[])))
+    wrong.eval().to("cuda")
+    with pytest.raises(_lib.SrhError):
+        wrong.import_packed(buf)
+    with torch.no_grad():
+        next(other.parameters()).add_(1.0)
+    with pytest.raises(_lib.SrhError):
+        other.infer_masks_and_img_features(rgb)

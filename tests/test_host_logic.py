@@ -118,9 +118,11 @@ def test_queries_with_tied_cutoff_match_reference_kdtree():
     pts = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
     pts = pts[rng.random(len(pts)) < 0.8].astype(np.int64)          # holes break the symmetry
     infos = get_patch_info_one_img(0, 384, 0, 256, 3)
-    allq = build_all_patch_queries(pts, infos, 0, len(infos), cfg)
-    n_src = 0
-    for info, (a_ids, a_p, a_pairs, a_valid) in zip(infos, allq):
+    fq = build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+    n_src = n_tied = 0
+    for t, info in enumerate(infos):
+        a_ids, a_p, a_pairs, a_valid = fq.tile(t)
+        tied = fq.tied[int(fq.offsets[t]):int(fq.offsets[t + 1])].astype(bool)
         r_ids, r_p, r_pairs, r_valid = oscene.build_patch_queries(pts, info, AttrDict(cfg))
         np.testing.assert_array_equal(a_ids, r_ids)
         np.testing.assert_array_equal(a_valid, r_valid)
@@ -129,7 +131,47 @@ def test_queries_with_tied_cutoff_match_reference_kdtree():
         for i in range(len(a_ids)):
             assert set(a_pairs[i, a_valid[i], 1].tolist()) == set(r_pairs[i, r_valid[i], 1].tolist()), (info, i)
             n_src += 1
-    assert n_src > 500
+        # rows with a tied cut-off were decided by the library's restatement of scipy's kd-tree (csrc/kdtree_emul.hpp): they
+        # equal the reference's call element for element, ORDER included
+        np.testing.assert_array_equal(a_pairs[tied], r_pairs[tied])
+        n_tied += int(tied.sum())
+    assert n_src > 500 and n_tied > 300
+
+
+def test_kdtree_restatement_matches_scipy():
+    """csrc/kdtree_emul.hpp against scipy itself: the tree's index permutation (tree.indices — i.e. which points share a leaf and
+    in which order, nth_element included) and the k-NN answers in scipy's output order, on data where ties are everywhere:
+    dense lattices with duplicate points, 8-pixel lattices, uniform integers, NMS-like point sets; random k / radius; query
+    points inside and outside the data."""
+    import ctypes as C
+    import scipy.spatial
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(0)
+    for case in range(240):
+        n = int(rng.integers(1, 700))
+        mode = case % 4
+        if mode == 0:
+            pts = rng.integers(0, int(rng.integers(2, 40)), size=(n, 2))
+        elif mode == 1:
+            pts = rng.integers(0, 64, size=(n, 2)) * 8
+        elif mode == 2:
+            pts = rng.integers(0, 513, size=(n, 2))
+        else:
+            side = int(np.ceil(np.sqrt(n))) + 2
+            allp = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2) * int(rng.integers(1, 20))
+            pts = allp[rng.permutation(len(allp))[:n]]
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        k, r = (17, 64.0) if case % 3 else (int(rng.integers(1, 24)), float(rng.integers(1, 120)))
+        q = np.ascontiguousarray(np.concatenate([pts, rng.integers(-30, 560, size=(8, 2)).astype(np.float64)]))
+        tree = scipy.spatial.KDTree(pts)                     # the reference's class and defaults (leafsize 10)
+        _, want = tree.query(q, k=k, distance_upper_bound=r)
+        want = np.asarray(want).reshape(len(q), k)
+        got = np.zeros((len(q), k), dtype=np.int32)
+        perm = np.zeros(len(pts), dtype=np.int32)
+        assert lib.srh_kdtree_knn_host(vp(pts), len(pts), 10, vp(q), len(q), k, r, vp(got), vp(perm)) == 0
+        np.testing.assert_array_equal(perm, tree.indices)
+        np.testing.assert_array_equal(got, want)
 
 
 def test_mask_candidates_match_numpy_where():

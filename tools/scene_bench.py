@@ -8,7 +8,8 @@ The final map_decoder bias is lowered so that the random network yields sparse m
 
     python tools/scene_bench.py [--bias -2.2] [--wscale 16] [--batch 64] [--iters 3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/scene_bench.py    # N GPUs:
-        tiles sharded over the ranks (RCCL: weight broadcast, canvas reduce, point broadcast, vote gather); rank 0 prints
+        tiles sharded over the ranks (RCCL: packed-weight broadcast, banded canvas reduce, point broadcast, vote gather);
+        rank 0 prints ms/scene (max over ranks) and the per-rank stage times
 """
 import argparse
 import json
@@ -56,11 +57,13 @@ def main():
             sd[k] = 0.02 * torch.randn(v.shape, generator=g)
     sd["map_decoder.7.weight"] = args.wscale * torch.randn(sd["map_decoder.7.weight"].shape, generator=g)
     sd["map_decoder.7.bias"] = torch.full_like(sd["map_decoder.7.bias"], args.bias)
-    if world > 1:
-        from sam_road_amd.distributed import broadcast_state_dict
-        sd = broadcast_state_dict(sd, src=0, device=dev)      # one flat RCCL broadcast over xGMI (every rank seeded identically anyway)
-    net.load_state_dict(sd, strict=True)
+    if rank == 0:
+        net.load_state_dict(sd, strict=True)
     net.eval().to(dev)
+    t_w = time.perf_counter()
+    net.share_packed_weights(src=0)          # N > 1: rank 0 packs once, the packed fp16 arena is broadcast over RCCL / xGMI
+    torch.cuda.synchronize()
+    t_w = time.perf_counter() - t_w
     rng = np.random.default_rng(0)
     coarse = rng.integers(0, 256, size=(2048 // 8, 2048 // 8, 3)).astype(np.float32)
     img = np.kron(coarse, np.ones((8, 8, 1), np.float32)).astype(np.uint8)
@@ -124,7 +127,15 @@ def main():
             pass
         torch.cuda.synchronize()
         piped48 = (time.perf_counter() - t0) / 48
+    per_rank = None
     if world > 1:
+        # per-rank stage times (ms): pass 1 of the rank's tile chunk, its pass-2 share, the whole call — gathered on rank 0
+        mine = torch.tensor([1e3 * p1, 1e3 * acc["edge_votes"] / args.iters, 1e3 * acc["extract_graph_points"] / args.iters, 1e3 * full,
+                             float(hi - lo)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(zip(("ms_pass1_own_tiles", "ms_edge_votes", "ms_extract_graph_points", "ms_full", "tiles"),
+                             [round(v, 2) for v in a.tolist()])) for a in allr]
         t = torch.tensor([p1, full], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         p1, full = t.tolist()
@@ -134,6 +145,7 @@ def main():
         return
     nodes, edges, kp, road = res
     print(json.dumps({"scene": "synthetic 2048x2048 u8, 256 tiles of 512^2 (16x16, margin 64)", "n_gpus": world,
+                      "ms_weight_share": round(1e3 * t_w, 2) if world > 1 else None, "per_rank": per_rank,
                       "infer_batch_size": args.batch, "ms_per_scene_pass1": round(1e3 * p1, 2),
                       "tiles_per_s_pass1": round(256 / p1, 1), "ms_per_scene_full": round(1e3 * full, 2),
                       "ms_per_scene_pipelined": None if piped is None else round(1e3 * piped, 2), "pipelined_runs_of_12_scenes": piped_runs,

@@ -65,14 +65,58 @@ __device__ __forceinline__ void read_kfrag(f16x8 (&kf)[4], const char* k_lds, in
 // rel_w enters as the C operand of the first MFMA (no accumulator init), rel_h — one or two scalars per tile — is folded
 // into the row-max and into the addend of the exp argument's FMA, the row sum uses packed adds.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// row max of one key tile's 16 scores per lane, rel_h included (before the cross-half exchange).
+// key rows of the lane's 16 scores: WIN 32: one window row per tile; WIN 16: r < 8 -> row 0, r >= 8 -> row 1;
+// WIN 14: keys 0..13 / 14..27 -> r < 6 row 0, r = 6, 7 row `half`, r = 8..11 row 1, r >= 12: row 1 (half 0) / no key (half 1)
 template <int WIN>
-__device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], const char* vt_lds,
-                                          float rh0, float rh1, float c_exp, int lane) {
-    const int half = lane >> 5, row = lane & 31;
-    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
+__device__ __forceinline__ float tile_max(const f32x16& s, float rh0, float rh1, int half) {
+    if (WIN == 32) {
+        float m = s[0];
 #pragma unroll
-    for (int ks = 1; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
-    f16x8 vf[2][2];
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, s[r]);
+        return m + rh0;
+    } else if (WIN == 16) {
+        float ma = s[0], mb = s[8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, s[r]); mb = fmaxf(mb, s[8 + r]); }
+        return fmaxf(ma + rh0, mb + rh1);
+    } else {
+        const float rhm = half ? rh1 : rh0;                          // rel_h of r = 6, 7
+        float ma = s[0], mb = s[8];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) ma = fmaxf(ma, s[r]);
+#pragma unroll
+        for (int r = 9; r < 12; ++r) mb = fmaxf(mb, s[r]);
+        const float mt = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
+        mb = fmaxf(mb, half ? -INFINITY : mt);                       // rows 28..31 are not keys
+        return fmaxf(fmaxf(ma + rh0, mb + rh1), fmaxf(s[6], s[7]) + rhm);
+    }
+}
+
+// P^T = exp2(s * c_exp + rel_h * c_exp - m_new * c_exp) of one key tile as the B fragment of the P.V product (fp16), and its row sum
+template <int WIN>
+__device__ __forceinline__ void tile_exp(const f32x16& s, float rh0, float rh1, float m_new, float c_exp, int half,
+                                         f16x8 (&pb)[2], f32x2& sum2) {
+    const float mc = -m_new * c_exp;
+    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = WIN == 32 ? mc0 : fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
+    const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;  // r >= 12: exp2(-inf) = 0 for the rows that are not keys
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 pv;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int rr = r + e;
+            const float ad = WIN == 32 ? mc0 : WIN == 16 ? (rr >= 8 ? mc1 : mc0) : (rr < 6 ? mc0 : rr < 8 ? mcm : rr < 12 ? mc1 : mct);
+            pv[e] = __builtin_amdgcn_exp2f(fmaf(s[rr], c_exp, ad));   // raw v_exp_f32: exp2(-inf) = 0
+            pb[rr >> 3][rr & 7] = (f16)pv[e];
+        }
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(sum2) : "v"(pv));      // hipcc scalarises a plain f32x2 add here
+    }
+}
+
+__device__ __forceinline__ void read_vfrag(f16x8 (&vf)[2][2], const char* vt_lds, int lane) {
+    const int half = lane >> 5, row = lane & 31;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -81,31 +125,10 @@ __device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], cons
             const int c = (sx * 2 + half) ^ ((d >> 2) & 3);
             vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + d * 64 + c * 16);
         }
-    __builtin_amdgcn_sched_barrier(0);
-    // key rows of the lane's 16 scores: WIN 32: one window row per tile; WIN 16: r < 8 -> row 0, r >= 8 -> row 1;
-    // WIN 14: keys 0..13 / 14..27 -> r < 6 row 0, r = 6, 7 row `half`, r = 8..11 row 1, r >= 12: row 1 (half 0) / no key (half 1)
-    const float rhm = WIN == 14 ? (half ? rh1 : rh0) : rh0;        // rel_h of r = 6, 7
-    float mloc;
-    if (WIN == 32) {
-        mloc = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-        mloc += rh0;
-    } else if (WIN == 16) {
-        float ma = s[0], mb = s[8];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, s[r]); mb = fmaxf(mb, s[8 + r]); }
-        mloc = fmaxf(ma + rh0, mb + rh1);
-    } else {
-        float ma = s[0], mb = s[8];
-#pragma unroll
-        for (int r = 1; r < 6; ++r) ma = fmaxf(ma, s[r]);
-#pragma unroll
-        for (int r = 9; r < 12; ++r) mb = fmaxf(mb, s[r]);
-        float mt = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
-        mb = fmaxf(mb, half ? -INFINITY : mt);                   // rows 28..31 are not keys
-        mloc = fmaxf(fmaxf(ma + rh0, mb + rh1), fmaxf(s[6], s[7]) + rhm);
-    }
+}
+
+// running max / rescale shared by the one- and two-tile forms: returns the new max (raw units)
+__device__ __forceinline__ float update_max(QState& st, float mloc, float c_exp) {
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(st.m, mloc);
     // rescale the running state only when some lane's max moved (wave-uniform branch; after the first
@@ -119,28 +142,64 @@ __device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], cons
             for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
         st.m = m_new;
     }
-    const float mc = -m_new * c_exp;
-    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = WIN == 32 ? mc0 : fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
-    const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;  // r >= 12: exp2(-inf) = 0 for the rows that are not keys
+    return m_new;
+}
+
+template <int WIN>
+__device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], const char* vt_lds,
+                                          float rh0, float rh1, float c_exp, int lane) {
+    const int half = lane >> 5;
+    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
+    f16x8 vf[2][2];
+    read_vfrag(vf, vt_lds, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m_new = update_max(st, tile_max<WIN>(s, rh0, rh1, half), c_exp);
     f32x2 sum2 = {0.f, 0.f};
     f16x8 pb[2];
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        f32x2 pv;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int rr = r + e;
-            const float ad = WIN == 32 ? mc0 : WIN == 16 ? (rr >= 8 ? mc1 : mc0) : (rr < 6 ? mc0 : rr < 8 ? mcm : rr < 12 ? mc1 : mct);
-            pv[e] = __builtin_amdgcn_exp2f(fmaf(s[rr], c_exp, ad));   // raw v_exp_f32: exp2(-inf) = 0
-            pb[rr >> 3][rr & 7] = (f16)pv[e];
-        }
-        asm("v_pk_add_f32 %0, %0, %1" : "+v"(sum2) : "v"(pv));      // hipcc scalarises a plain f32x2 add here
-    }
+    tile_exp<WIN>(s, rh0, rh1, m_new, c_exp, half, pb, sum2);
     st.l += sum2[0] + sum2[1];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) st.o[dt] = mfma32(vf[dt][sx], pb[sx], st.o[dt]);
+}
+
+// TWO 32-row key tiles at once (round 3).  A wave's key loop was bound by the dependency CHAIN of one tile, not by any
+// pipe: four dependent S^T MFMAs (64 clk of latency each at 32 clk of issue), the 16-deep row-max tree, the cross-half
+// exchange (an LDS round trip), the exps, then two 2-deep P.V chains — about 1000 clk end to end with one more wave per SIMD to
+// fill the gaps (2470 clk per tile and wave measured, MFMA busy 21 %, VALU ~50 %).  With two tiles in flight the two S^T chains
+// interleave (the matrix pipe is paced instead of waiting on its own result), the two max trees are independent, there is ONE
+// exchange / rescale decision / row-sum update per 64 keys, twice as many independent exps per dependency level, and the
+// eight P.V MFMAs alternate between the two O^T accumulators.  Same arithmetic as two attn_tile calls except that both tiles
+// are exponentiated against the max over all 64 keys.
+template <int WIN>
+__device__ __forceinline__ void attn_tile2(QState& st, const f16x8 (&kfa)[4], const f16x8 (&kfb)[4], const char* vta, const char* vtb,
+                                           float rh0a, float rh1a, float rh0b, float rh1b, float c_exp, int lane) {
+    const int half = lane >> 5;
+    f32x16 sa = mfma32(kfa[0], st.q[0], st.relw);
+    f32x16 sb = mfma32(kfb[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) { sa = mfma32(kfa[ks], st.q[ks], sa); sb = mfma32(kfb[ks], st.q[ks], sb); }
+    f16x8 vfa[2][2], vfb[2][2];
+    read_vfrag(vfa, vta, lane);
+    read_vfrag(vfb, vtb, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m_new = update_max(st, fmaxf(tile_max<WIN>(sa, rh0a, rh1a, half), tile_max<WIN>(sb, rh0b, rh1b, half)), c_exp);
+    f32x2 sum2 = {0.f, 0.f};
+    f16x8 pa[2], pb[2];
+    tile_exp<WIN>(sa, rh0a, rh1a, m_new, c_exp, half, pa, sum2);
+    tile_exp<WIN>(sb, rh0b, rh1b, m_new, c_exp, half, pb, sum2);
+    st.l += sum2[0] + sum2[1];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) st.o[dt] = mfma32(vfa[dt][sx], pa[sx], st.o[dt]);
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) st.o[dt] = mfma32(vfb[dt][sx], pb[sx], st.o[dt]);
 }
 
 template <int WIN>
@@ -403,18 +462,21 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
             }
         }
         if (p.ablate != 1) {
+            // tiles 0..5 as three PAIRS (attn_tile2: two independent S^T chains / max trees in flight, one exchange and rescale
+            // decision per 56 keys), then tile 6.  The next pair's K fragments are read right behind the current pair's call: by then
+            // its S^T MFMAs have consumed the registers, and the reads' latency hides behind the pair's softmax
             f16x8 kfA[4], kfB[4];
             read_kfrag(kfA, k_lds, lane);
+            read_kfrag(kfB, k_lds + 4096, lane);
+            const float* rhq = rh + (lane & 31) * 17;
 #pragma unroll 1
-            for (int t = 0; t < 6; t += 2) {     // tiles 0..5 in pairs (next tile's K fragments prefetched), then tile 6
-                float rh0 = rh[(lane & 31) * 17 + 2 * t], rh1 = rh[(lane & 31) * 17 + 2 * t + 1];
-                read_kfrag(kfB, k_lds + (t + 1) * 4096, lane);
-                attn_tile<WIN>(st, kfA, vt_lds + t * 4096, rh0, rh1, c_exp, lane);
-                rh0 = rh[(lane & 31) * 17 + 2 * t + 2]; rh1 = rh[(lane & 31) * 17 + 2 * t + 3];
+            for (int t = 0; t < 6; t += 2) {
+                const float rh0a = rhq[2 * t], rh1a = rhq[2 * t + 1], rh0b = rhq[2 * t + 2], rh1b = rhq[2 * t + 3];
+                attn_tile2<WIN>(st, kfA, kfB, vt_lds + t * 4096, vt_lds + (t + 1) * 4096, rh0a, rh1a, rh0b, rh1b, c_exp, lane);
                 read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
-                attn_tile<WIN>(st, kfB, vt_lds + (t + 1) * 4096, rh0, rh1, c_exp, lane);
+                if (t < 4) read_kfrag(kfB, k_lds + (t + 3) * 4096, lane);
             }
-            attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rh[(lane & 31) * 17 + 12], rh[(lane & 31) * 17 + 13], c_exp, lane);
+            attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rhq[12], rhq[13], c_exp, lane);
         }
         store_query(st, p, tok, head, lane, valid);
         __builtin_amdgcn_wave_barrier();
@@ -494,12 +556,9 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
             f16x8 kfA[4], kfB[4]; \
             read_kfrag(kfA, base, lane); \
             read_kfrag(kfB, base + 4096, lane); \
-            float rh0 = rhp[((buf) * 2) * RPT]; \
-            float rh1 = RPT == 2 ? rhp[((buf) * 2) * RPT + 1] : 0.f; \
-            attn_tile<WIN>(st, kfA, base + 8192, rh0, rh1, c_exp, lane); \
-            rh0 = rhp[((buf) * 2 + 1) * RPT]; \
-            rh1 = RPT == 2 ? rhp[((buf) * 2 + 1) * RPT + 1] : 0.f; \
-            attn_tile<WIN>(st, kfB, base + 8192 + 4096, rh0, rh1, c_exp, lane); \
+            const float rh0a = rhp[((buf) * 2) * RPT], rh1a = RPT == 2 ? rhp[((buf) * 2) * RPT + 1] : 0.f; \
+            const float rh0b = rhp[((buf) * 2 + 1) * RPT], rh1b = RPT == 2 ? rhp[((buf) * 2 + 1) * RPT + 1] : 0.f; \
+            attn_tile2<WIN>(st, kfA, kfB, base + 8192, base + 8192 + 4096, rh0a, rh1a, rh0b, rh1b, c_exp, lane); \
         } \
         if (p.ablate != 2 && p.ablate != 8) SRH_STORE_STAGE((buf) ^ 1) \
         if (p.ablate != 8) __syncthreads(); }

@@ -4,10 +4,13 @@
 // C operand of the first S MFMA, rel_h folded into the row max / exp addend, pad tokens are real keys with k = b_k,
 // v = b_v, pad queries are skipped), generalised over the number of 16-wide k steps (KS = HD / 16 = 5) and of 32-row
 // O^T tiles (NDT = ceil(HD / 32) = 3, rows HD..95 are zero rows of V^T).  All keys of the window (<= 256) are staged in
-// LDS once per (image, head, window): K rows with a 16-byte pad (176-byte stride: 16 consecutive rows start in 16
-// different 4-bank groups, so the ds_read_b128 fragment reads are conflict-free without a swizzle), V^T tiles in
-// attention.hip's key-permuted layout (4-key x 8-dim blocks transposed with v_perm_b32).  This replaces the f32 VALU
-// fallback (attn_generic_kernel), which took 7.3 of the 14.4 ms of a ViT-H step.
+// LDS once per (image, head, window): K rows at their natural 160-byte stride with the 16-byte chunk index XORed with bit 3
+// of the row (rows r and r + 8 start in the same banks; the XOR moves one of them by four banks, which makes the ds_read_b128
+// fragment reads of every 16-lane service group conflict-free), V^T tiles in attention.hip's key-permuted layout (4-key x
+// 8-dim blocks transposed with v_perm_b32) holding only the HD real rows.  Round 3 trimmed the LDS image from 91 to 77.5 KiB
+// (no K pad, no zero rows, a 15-float rel-pos row) so that TWO workgroups fit a CU: at B = 8 the launch is 512 workgroups,
+// i.e. two rounds of one workgroup per CU with nothing to overlap a workgroup's staging phase became one round of two.
+// This replaces the f32 VALU fallback (attn_generic_kernel), which took 7.3 of the 14.4 ms of a ViT-H step.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -41,31 +44,16 @@ struct QStateX {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// one 32-row key tile (see attention.hip attn_tile; identical arithmetic with KS k steps and NDT output tiles)
-template <int WIN, int KS, int NDT>
-__device__ __forceinline__ void hx_tile(QStateX<KS, NDT>& st, const f16x8 (&kf)[KS], const char* vt_lds, float rh0, float rh1,
-                                        float c_exp, int lane) {
-    const int half = lane >> 5, row = lane & 31;
-    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
-#pragma unroll
-    for (int ks = 1; ks < KS; ++ks) s = mfma32(kf[ks], st.q[ks], s);
-    f16x8 vf[NDT][2];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            const int c = (sx * 2 + half) ^ ((row >> 2) & 3);
-            vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + dt * 2048 + row * 64 + c * 16);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    const float rhm = WIN == 14 ? (half ? rh1 : rh0) : rh0;
-    float mloc;
+// the pieces of a key tile's softmax (attention.hip tile_max / tile_exp / update_max, for WIN 14 / 16 and NDT output tiles)
+template <int WIN>
+__device__ __forceinline__ float hx_tile_max(const f32x16& s, float rh0, float rh1, int half) {
     if (WIN == 16) {
         float ma = s[0], mb = s[8];
 #pragma unroll
         for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, s[r]); mb = fmaxf(mb, s[8 + r]); }
-        mloc = fmaxf(ma + rh0, mb + rh1);
+        return fmaxf(ma + rh0, mb + rh1);
     } else {
+        const float rhm = half ? rh1 : rh0;
         float ma = s[0], mb = s[8];
 #pragma unroll
         for (int r = 1; r < 6; ++r) ma = fmaxf(ma, s[r]);
@@ -73,8 +61,28 @@ __device__ __forceinline__ void hx_tile(QStateX<KS, NDT>& st, const f16x8 (&kf)[
         for (int r = 9; r < 12; ++r) mb = fmaxf(mb, s[r]);
         const float mt = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
         mb = fmaxf(mb, half ? -INFINITY : mt);                   // rows 28..31 are not keys
-        mloc = fmaxf(fmaxf(ma + rh0, mb + rh1), fmaxf(s[6], s[7]) + rhm);
+        return fmaxf(fmaxf(ma + rh0, mb + rh1), fmaxf(s[6], s[7]) + rhm);
     }
+}
+
+template <int WIN>
+__device__ __forceinline__ float hx_tile_exp(const f32x16& s, float rh0, float rh1, float m_new, float c_exp, int half, f16x8 (&pb)[2]) {
+    const float mc = -m_new * c_exp;
+    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
+    const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float ad = WIN == 16 ? (r >= 8 ? mc1 : mc0) : (r < 6 ? mc0 : r < 8 ? mcm : r < 12 ? mc1 : mct);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c_exp, ad));
+        sum += pv;
+        pb[r >> 3][r & 7] = (f16)pv;
+    }
+    return sum;
+}
+
+template <int KS, int NDT>
+__device__ __forceinline__ float hx_update_max(QStateX<KS, NDT>& st, float mloc, float c_exp) {
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(st.m, mloc);
     if (__any(m_new != st.m)) {
@@ -86,32 +94,77 @@ __device__ __forceinline__ void hx_tile(QStateX<KS, NDT>& st, const f16x8 (&kf)[
             for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
         st.m = m_new;
     }
-    const float mc = -m_new * c_exp;
-    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
-    const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;
-    float sum = 0.f;
-    f16x8 pb[2];
+    return m_new;
+}
+
+template <int NDT>
+__device__ __forceinline__ void hx_read_vfrag(f16x8 (&vf)[NDT][2], const char* vt_lds, int lane) {
+    const int half = lane >> 5, row = lane & 31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float ad = WIN == 16 ? (r >= 8 ? mc1 : mc0) : (r < 6 ? mc0 : r < 8 ? mcm : r < 12 ? mc1 : mct);
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c_exp, ad));
-        sum += pv;
-        pb[r >> 3][r & 7] = (f16)pv;
-    }
-    st.l += sum;
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const int c = (sx * 2 + half) ^ ((row >> 2) & 3);
+            vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + dt * 2048 + row * 64 + c * 16);
+        }
+}
+
+// one 32-row key tile (see attention.hip attn_tile; identical arithmetic with KS k steps and NDT output tiles)
+template <int WIN, int KS, int NDT>
+__device__ __forceinline__ void hx_tile(QStateX<KS, NDT>& st, const f16x8 (&kf)[KS], const char* vt_lds, float rh0, float rh1,
+                                        float c_exp, int lane) {
+    const int half = lane >> 5;
+    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) s = mfma32(kf[ks], st.q[ks], s);
+    f16x8 vf[NDT][2];
+    hx_read_vfrag<NDT>(vf, vt_lds, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m_new = hx_update_max<KS, NDT>(st, hx_tile_max<WIN>(s, rh0, rh1, half), c_exp);
+    f16x8 pb[2];
+    st.l += hx_tile_exp<WIN>(s, rh0, rh1, m_new, c_exp, half, pb);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) st.o[dt] = mfma32(vf[dt][sx], pb[sx], st.o[dt]);
 }
 
+// two key tiles at once (attention.hip attn_tile2): the two S^T chains — KS = 5 dependent MFMAs each at head dim 80 — interleave,
+// one cross-half exchange / rescale decision per pair, the P.V MFMAs rotate over the NDT accumulators
+template <int WIN, int KS, int NDT>
+__device__ __forceinline__ void hx_tile2(QStateX<KS, NDT>& st, const f16x8 (&kfa)[KS], const f16x8 (&kfb)[KS], const char* vta,
+                                         const char* vtb, float rh0a, float rh1a, float rh0b, float rh1b, float c_exp, int lane) {
+    const int half = lane >> 5;
+    f32x16 sa = mfma32(kfa[0], st.q[0], st.relw);
+    f32x16 sb = mfma32(kfb[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) { sa = mfma32(kfa[ks], st.q[ks], sa); sb = mfma32(kfb[ks], st.q[ks], sb); }
+    f16x8 vfa[NDT][2], vfb[NDT][2];
+    hx_read_vfrag<NDT>(vfa, vta, lane);
+    hx_read_vfrag<NDT>(vfb, vtb, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m_new = hx_update_max<KS, NDT>(st, fmaxf(hx_tile_max<WIN>(sa, rh0a, rh1a, half), hx_tile_max<WIN>(sb, rh0b, rh1b, half)), c_exp);
+    f16x8 pa[2], pb[2];
+    const float suma = hx_tile_exp<WIN>(sa, rh0a, rh1a, m_new, c_exp, half, pa);
+    const float sumb = hx_tile_exp<WIN>(sb, rh0b, rh1b, m_new, c_exp, half, pb);
+    st.l += suma + sumb;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) st.o[dt] = mfma32(vfa[dt][sx], pa[sx], st.o[dt]);
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) st.o[dt] = mfma32(vfb[dt][sx], pb[sx], st.o[dt]);
+}
+
 // grid = (image, head, window); 4 waves; each wave walks 32-query tiles of the window's REAL tokens
 template <int HD, int WIN>
-__global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, WIN == 14 ? 2 : 1) void attn_hdx_kernel(AttnParams p) {
     constexpr int KS = HD / 16, NDT = (HD + 31) / 32, NT = GeomX<WIN>::NT, KPT = GeomX<WIN>::KPT, RPT = GeomX<WIN>::RPT;
-    constexpr int KROW = HD * 2 + 16, NCH = HD / 8;
-    constexpr int LDS_K = NT * 32 * KROW, LDS_VT = NT * NDT * 2048;
-    static_assert(HD % 16 == 0 && KROW % 16 == 0, "head dim must be a multiple of 16");
+    constexpr int KROW = HD * 2, NCH = HD / 8, VTT = HD * 64;      // bytes per K row / per V^T key tile (HD rows x 32 keys x 2 B)
+    constexpr int LDS_K = NT * 32 * KROW, LDS_VT = NT * VTT + (32 * NDT - HD) * 64, RHS = WIN + 1;   // RHS: odd rel-pos row stride
+    static_assert(HD % 16 == 0 && (NCH % 2) == 0, "head dim must be a multiple of 16");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const k_lds = smem;
     char* const vt_lds = smem + LDS_K;
@@ -128,16 +181,10 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
     const int nreal = nry * nrx;
     const int ntq = (nreal + 31) / 32;
 
-    // ---- stage K rows and the transposed, key-permuted V^T tiles (pad positions: k = b_k, v = b_v; rows KPT..31 and the
-    // V^T rows HD..32*NDT-1 are zero)
-    // zero rows of V^T: d = HD .. 32 * NDT - 1 of every tile (the O^T rows that do not exist)
-    if (HD % 32 != 0) {
-        constexpr int ZROWS = 32 * NDT - HD;                     // rows HD % 32 .. 31 of the last d tile, 64 B each
-        for (int i = tid; i < NT * ZROWS * 4; i += 256) {
-            const int t = i / (ZROWS * 4), q = i % (ZROWS * 4);
-            reinterpret_cast<uint4*>(vt_lds + (t * NDT + NDT - 1) * 2048 + (HD % 32) * 64)[q] = make_uint4(0, 0, 0, 0);
-        }
-    }
+    // ---- stage K rows and the transposed, key-permuted V^T tiles (pad positions: k = b_k, v = b_v; key rows KPT..31 are zero)
+    // (V^T rows HD .. 32 * NDT - 1 do not exist: the last d tile's fragment reads run into the next key tile — or, for the last
+    // one, into the 1 KiB pad behind the array — and produce garbage O^T rows d >= HD, which are never stored; every O^T row
+    // depends on its own V^T row only)
     auto key_src = [&](int t, int i) -> const f16* {             // qkv row of local key i of tile t (pad position: the bias row)
         int rr, cc;
         hx_tile_rc<WIN>(i, rr, cc);
@@ -148,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
         const int c = item % NCH, i = (item / NCH) & 31, t = item / (NCH * 32);
         uint4 kv = make_uint4(0, 0, 0, 0);
         if (i < KPT) kv = *reinterpret_cast<const uint4*>(key_src(t, i) + D + head * HD + c * 8);
-        *reinterpret_cast<uint4*>(k_lds + (t * 32 + i) * KROW + c * 16) = kv;
+        *reinterpret_cast<uint4*>(k_lds + (t * 32 + i) * KROW + (c ^ ((i >> 3) & 1)) * 16) = kv;
     }
     // V: 4 keys x 8 dims per item -> 8 dims x 4 keys: every output word pairs the same fp16 of two keys = one v_perm_b32
     for (int item = tid; item < NT * 8 * NCH; item += 256) {
@@ -167,19 +214,19 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
         const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&v[3]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int d = c * 8 + e, dt = d >> 5, dl = d & 31;
+            const int d = c * 8 + e, dl = d & 31;
             const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
             uint2 w;
             w.x = __builtin_amdgcn_perm(w1[e >> 1], w0[e >> 1], sel);
             w.y = __builtin_amdgcn_perm(w3[e >> 1], w2[e >> 1], sel);
-            *reinterpret_cast<uint2*>(vt_lds + (t * NDT + dt) * 2048 + dl * 64 + ((sc ^ ((dl >> 2) & 3)) * 16) + eo * 2) = w;
+            *reinterpret_cast<uint2*>(vt_lds + t * VTT + d * 64 + ((sc ^ ((dl >> 2) & 3)) * 16) + eo * 2) = w;
         }
     }
     __syncthreads();
 
     const float c_exp = p.scale * 1.4426950408889634f;
     const float inv_scale = 1.0f / p.scale;
-    float* const rh = rh_lds + wave * 32 * 17;
+    float* const rh = rh_lds + wave * 32 * RHS;
     for (int jt = wave; jt < ntq; jt += 4) {
         const int qi_raw = jt * 32 + (lane & 31);
         const bool valid = qi_raw < nreal;
@@ -215,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int jrow = mfma32_row(r, lane);
                 const int k = qc - jrow + WIN - 1;
-                if (k >= 0 && k < WIN && jrow < 2 * WIN - 1) rh[(lane & 31) * 17 + k] = acc[r] * inv_scale;
+                if (k >= 0 && k < WIN && jrow < 2 * WIN - 1) rh[(lane & 31) * RHS + k] = acc[r] * inv_scale;
             }
             __builtin_amdgcn_wave_barrier();
             if (pass == 0) {
@@ -223,19 +270,28 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) {
                     int rr, cc;
                     hx_tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
-                    st.relw[r] = (cc < WIN) ? rh[(lane & 31) * 17 + cc] : 0.f;
+                    st.relw[r] = (cc < WIN) ? rh[(lane & 31) * RHS + cc] : 0.f;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-#pragma unroll 1
-        for (int t = 0; t < NT; ++t) {
-            f16x8 kf[KS];
+        auto read_kf = [&](f16x8 (&kf)[KS], int t) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                kf[ks] = *reinterpret_cast<const f16x8*>(k_lds + (t * 32 + (lane & 31)) * KROW + (ks * 2 + half) * 16);
-            const float rh0 = rh[(lane & 31) * 17 + t * RPT], rh1 = rh[(lane & 31) * 17 + t * RPT + 1];
-            hx_tile<WIN, KS, NDT>(st, kf, vt_lds + t * NDT * 2048, rh0, rh1, c_exp, lane);
+                kf[ks] = *reinterpret_cast<const f16x8*>(k_lds + (t * 32 + (lane & 31)) * KROW + (((ks * 2 + half) ^ ((lane >> 3) & 1)) * 16));
+        };
+        const float* rhq = rh + (lane & 31) * RHS;
+        f16x8 kfa[KS], kfb[KS];
+#pragma unroll 1
+        for (int t = 0; t + 1 < NT; t += 2) {                   // key tiles in pairs
+            read_kf(kfa, t);
+            read_kf(kfb, t + 1);
+            hx_tile2<WIN, KS, NDT>(st, kfa, kfb, vt_lds + t * VTT, vt_lds + (t + 1) * VTT, rhq[t * RPT], rhq[t * RPT + 1],
+                                   rhq[(t + 1) * RPT], rhq[(t + 1) * RPT + 1], c_exp, lane);
+        }
+        if (NT & 1) {                                           // the odd last tile (7 tiles per 14 x 14 window)
+            read_kf(kfa, NT - 1);
+            hx_tile<WIN, KS, NDT>(st, kfa, vt_lds + (NT - 1) * VTT, rhq[(NT - 1) * RPT], rhq[(NT - 1) * RPT + 1], c_exp, lane);
         }
         const float inv = 1.0f / (st.l + __shfl_xor(st.l, 32, 64));
         if (valid) {
@@ -260,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_hdx_kernel(AttnParams p) {
 template <int HD, int WIN>
 int hdx_launch(const AttnParams& p, hipStream_t s) {
     constexpr int NDT = (HD + 31) / 32, NT = GeomX<WIN>::NT;
-    constexpr int lds = NT * 32 * (HD * 2 + 16) + NT * NDT * 2048 + 4 * 32 * 17 * 4;
+    constexpr int lds = NT * 32 * HD * 2 + NT * HD * 64 + (32 * NDT - HD) * 64 + 4 * 32 * (WIN + 1) * 4;   // WIN 14: 78.5 KiB = two per CU
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_hdx_kernel<HD, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -48,6 +48,11 @@ def nms_points(points, scores, radius, return_indices=False):
                             "(np.where of the u8 masks, *_NMS_RADIUS of the YAMLs)")
         xy = np.ascontiguousarray(pts, dtype=np.int32)
         force = np.ascontiguousarray(sc > 1.0, dtype=np.uint8)
+        if force.all():
+            # every candidate is force-kept (graph_utils.py:586 `kept[nbr] = sc[nbr] > 1.0`): with the u8 mask scores of the first
+            # two calls of extract_graph_points that is ALWAYS the case — the reference's loop then suppresses nothing and the call
+            # only re-orders the candidates.  No neighbour search (it was 3/4 of mask -> points).
+            return (pts, order) if return_indices else pts
         rc = _lib.load().srh_nms_points_host(xy.ctypes.data_as(C.c_void_p), force.ctypes.data_as(C.c_void_p), n,
                                              int(radius), kept.ctypes.data_as(C.c_void_p))
         if rc != 0:

@@ -50,7 +50,10 @@ int main(int argc, char** argv) {
     const int D = 768;
     const Shape all[] = {{"qkv", T, 3 * D, D, 0, false, true}, {"proj", T, D, D, 0, true, false},
                          {"fc1", T, 4 * D, D, 1, false, true}, {"fc2", T, D, 4 * D, 0, true, false},
-                         {"hproj", T, D, D, 0, false, true}, {"hfc2", T, D, 4 * D, 0, false, true}};
+                         {"hproj", T, D, D, 0, false, true}, {"hfc2", T, D, 4 * D, 0, false, true},
+                         // ViT-H at 256 px, B = 8 (BASELINE configs[4]): M = 2048 tokens, D = 1280 — the small-M regime of gemm_glds_kernel
+                         {"vh_qkv", 2048, 3840, 1280, 0, false, true}, {"vh_proj", 2048, 1280, 1280, 0, true, false},
+                         {"vh_fc1", 2048, 5120, 1280, 1, false, true}, {"vh_fc2", 2048, 1280, 5120, 0, true, false}};
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     for (const Shape& s : all) {

@@ -166,21 +166,27 @@ def main():
         ctx = _lib.Context.get(local_rank)
         stream = torch.cuda.current_stream(dev).cuda_stream
         torch.cuda.synchronize(dev)
-        # an event pair around a launch measures the kernel PLUS the packet processing around it: calibrate that on a kernel of
-        # known duration (same stream, idle device) and subtract it per launch, so the per-class times are kernel durations
-        # (they reproduce the rocprofv3 --kernel-trace averages of profiles/, and their sum stays below ms_per_step)
+        # Per-class GPU time: HIP events around every launch on the launch stream, in a separate pass over the same steps (the first
+        # instrumented step creates the event pool and is discarded).  Two facts about these numbers, both checked against
+        # `rocprofv3 --kernel-trace --stats` of this command (profiles/r03_event_overhead_check.txt):
+        #  * the event-to-event time of a launch IS its rocprofv3 duration to within ~1 % — the figures below are reported as measured;
+        #  * the instrumented pass (like a profiled run) is slower than the timed region above: the marker packets serialise the
+        #    queue, so the classes sum to the instrumented pass's own step time (`instrumented_ms_per_step`), not to `ms_per_step`.
+        # `event_overhead_us_per_launch` (srh_profile_overhead: event pair around a kernel of known duration) is what subtracting
+        # the packet handling would remove; `achieved_if_overhead_subtracted` shows the effect on the GEMM figure.
         ovh = ctx.profile_overhead(stream)
         nrep = max(1, min(args.steps, 5))
         ctx.profile_enable(True)
         step()                                      # first instrumented step creates the event pool: discarded
         ctx.profile_read()
+        torch.cuda.synchronize(dev)
+        t_i = time.perf_counter()
         for _ in range(nrep):
             step()
+        torch.cuda.synchronize(dev)
+        instrumented_ms = 1e3 * (time.perf_counter() - t_i) / nrep
         rows = ctx.profile_read()
         ctx.profile_enable(False)
-        for r in rows:
-            r["ms_raw"] = r["ms"]
-            r["ms"] = max(r["ms"] - r["launches"] * ovh, 0.25 * r["ms"])
 
         def agg(sel):
             fl, ms, n = sum(r["flops"] for r in sel), sum(r["ms"] for r in sel), sum(r["launches"] for r in sel)
@@ -223,8 +229,11 @@ def main():
                                                "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 5),
                                                "algorithmic_flops_per_launch": round(d_fl / max(d_n, 1), 1)},
                            "share_of_gpu_time": round(ms / total_ms, 4) if total_ms else None,
-                           "timing": "HIP events around every launch on the launch stream, minus the calibrated per-launch event overhead",
+                           "timing": "HIP events around every launch on the launch stream (separate instrumented pass; agrees with rocprofv3 "
+                                     "--kernel-trace durations to ~1 %)",
                            "event_overhead_us_per_launch": round(ovh * 1e3, 3),
+                           "achieved_if_overhead_subtracted": round(fl / (max(ms - n * ovh, 1e-9) * 1e-3) / 1e12, 2) if ms > 0 else None,
+                           "instrumented_ms_per_step": round(instrumented_ms, 4),
                            "sum_of_classes_ms_per_step": round(total_ms / nrep, 4),
                            "by_class_ms_per_step": {r["name"]: round(r["ms"] / nrep, 4) for r in rows}}
         if traffic_note:

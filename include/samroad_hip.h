@@ -151,9 +151,9 @@ typedef struct {
 } srh_profile_row;
 int srh_profile_enable(srh_ctx* ctx, int on);
 int srh_profile_read(srh_ctx* ctx, srh_profile_row* rows, int max_rows, int* n_rows);
-/* Calibration of the above: the time an event pair adds around ONE launch — median over 32 launches of a kernel that spins
- * for exactly 50 us of the 100 MHz wall clock, minus those 50 us and the kernel's own 1.5 us of ramp — which a caller subtracts per launch to turn
- * event-bracketed times into kernel durations (bench.py's roofline pass; checked against rocprofv3 in profiles/). */
+/* Calibration of the above: what an event pair around ONE launch adds beyond the time the kernel's waves run — median over 32
+ * launches of a kernel that spins for exactly 50 us of the 100 MHz wall clock, minus those 50 us (dispatch, completion and the
+ * marker packets; rocprofv3 counts most of it as kernel duration as well).  bench.py reports it next to its event-timed classes. */
 int srh_profile_overhead(srh_ctx* ctx, void* stream, double* ms_per_launch);
 
 /* ---- host-side geometry between the two GPU passes (no device work, callable without a GPU) ---------------

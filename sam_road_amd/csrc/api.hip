@@ -990,11 +990,11 @@ __global__ void srh_spin_kernel(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
 }
 
-// What an event pair around ONE launch adds to the launch's own duration: median over 32 launches of (event-to-event time
-// around a kernel whose single wave spins for exactly 50 us) - 50 us - 1.5 us, measured on `stream` with the device otherwise
-// idle.  The 1.5 us are the spin kernel's own dispatch-to-first-wave and last-wave-to-completion time, which rocprofv3 counts
-// as kernel duration for every kernel (checked against `rocprofv3 --kernel-trace --stats` of the same bench.py run:
-// profiles/r03_event_overhead_check.txt — the per-class sums agree within 2 %).
+// What an event pair around ONE launch adds beyond the time the kernel's waves run: median over 32 launches of (event-to-event
+// time around a kernel whose single wave spins for exactly 50 us) - 50 us, measured on `stream` with the device otherwise idle
+// (~3 us on MI355X: dispatch-to-first-wave, last-wave-to-completion and the marker packets).  Informational: rocprofv3 counts
+// most of it as kernel duration too — bench.py's raw event times agree with `rocprofv3 --kernel-trace --stats` to ~1 %
+// (profiles/r03_event_overhead_check.txt).
 extern "C" int srh_profile_overhead(srh_ctx* c, void* stream, double* ms_per_launch) {
     if (!c || !ms_per_launch) return SRH_ERR_BAD_ARG;
     hipSetDevice(c->device);
@@ -1015,7 +1015,7 @@ extern "C" int srh_profile_overhead(srh_ctx* c, void* stream, double* ms_per_lau
     for (auto& x : ev) hipEventDestroy(x);
     if (e != hipSuccess) return hip_fail(c, e, "srh_profile_overhead");
     std::sort(d.begin(), d.end());
-    *ms_per_launch = std::max(0.0, (double)d[N / 2] - 0.050 - 0.0015);
+    *ms_per_launch = std::max(0.0, (double)d[N / 2] - 0.050);
     return 0;
 }
 

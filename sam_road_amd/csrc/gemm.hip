@@ -271,6 +271,94 @@ void gemm_glds_kernel(GemmParams p) {
     epilogue_staged<2, 0>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 128(M) x 160(N) x 64 LDS-DMA variant for the SMALL-M layers whose 128x128 tile count misses the chip's 512 workgroup slots
+// (two workgroups per CU): ViT-H at 256 px, B = 8 has M = 2048 rows, and fc1 (N = 5120) is 640 tiles of 128x128 = two rounds
+// with the second a quarter full, but exactly 512 tiles of 128x160 = ONE round.  Four waves stacked along M: wave tile 32(M) x 160(N) = 1 x 5 v_mfma_f32_32x32x16_f16 tiles (80
+// accumulators), 2 x (16 + 20) KiB LDS stages = 72 KiB, same DMA / swizzle / one-barrier-per-k-tile structure as the
+// 128x128 kernel above.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_glds160_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 160, ATILE = BM * BK * 2, WTILE = BN * BK * 2, STAGE = ATILE + WTILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, zsplit = blockIdx.y;
+    const int kt0 = zsplit * (p.K / BK) / nsplit, nk = (zsplit + 1) * (p.K / BK) / nsplit;
+
+    // DMA piece i of a wave covers rows i*32 + wave*8 .. +8 of a tile (8 rows x 128 B = 1 KiB): 4 pieces of A, 5 of W
+    const int prow = lane >> 3, pc = lane & 7;
+    const char* asrc[4];
+    const char* wsrc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = i * 32 + wave * 8 + prow;
+        const int c = pc ^ ((r >> 1) & 7);
+        if (i < 4) asrc[i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8);
+        wsrc[i] = reinterpret_cast<const char*>(p.W + (size_t)(n0 + r) * p.ldw + c * 8);
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+#define SRH_DMA_TILE160(kt, stage) { \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) { \
+        char* d_ = smem + (stage) * STAGE + (i * 32 + wave * 8) * 128; \
+        if (i < 4) __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)(kt) * (BK * 2)), (lds_ptr)d_, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc[i] + (size_t)(kt) * (BK * 2)), (lds_ptr)(d_ + ATILE), 16, 0, 0); } }
+
+    f32x16 acc[5][1];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int x_row0 = (wave * 32) * 128;
+
+    SRH_DMA_TILE160(kt0, 0)
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int stage = (kt - kt0) & 1;
+        __syncthreads();   // retires this wave's DMA (vmcnt(0)) and orders everyone's; frees stage^1
+        if (kt + 1 < nk) SRH_DMA_TILE160(kt + 1, stage ^ 1)
+        const char* sa = smem + stage * STAGE + x_row0;
+        const char* sw = smem + stage * STAGE + ATILE;
+        f16x8 fwA[5], fwB[5], fxA, fxB;
+#define SRH_FRAG160(fw, fx, ks) { fx = *reinterpret_cast<const f16x8*>(sa + foff[ks]); \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + i * 4096); }
+#define SRH_MMA160(fw, fx) { _Pragma("unroll") for (int i = 0; i < 5; ++i) acc[i][0] = mfma32(fw[i], fx, acc[i][0]); }
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG160(fwA, fxA, 0)
+        SRH_FRAG160(fwB, fxB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA160(fwA, fxA)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG160(fwA, fxA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA160(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG160(fwB, fxB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA160(fwA, fxA)
+        SRH_MMA160(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nsplit > 1) {  // raw f32 partial sums; bias / residual / activation are applied by splitk_reduce_kernel
+        GemmParams q = p;
+        q.bias = nullptr; q.resid = nullptr; q.pos = nullptr; q.act = 0; q.out_f16 = nullptr;
+        q.out_f32 = p.split_ws + (size_t)zsplit * p.M * p.N; q.ldc = p.N;
+        epilogue<5, 1>(q, acc, m0 + wave * 32, n0, lane);
+        return;
+    }
+    epilogue<5, 1>(p, acc, m0 + wave * 32, n0, lane);
+}
+
 // out = act(sum_z partial[z] + bias) (+ resid): the partial sums are added in ascending z (fixed order: deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     const size_t quad = (size_t)blockIdx.x * 256 + threadIdx.x;          // 4 consecutive columns
@@ -503,11 +591,22 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// Small-M layers: take 128x160 tiles (gemm_glds160_kernel) when more than one round of 128x128 tiles is one round of 128x160 tiles
+// (ViT-H fc1 at M = 2048: 640 -> 512 workgroups on 512 slots; measured 46.0 -> 41.3 us).  Not for the few-tile layers: proj / fc2 of
+// ViT-H as 128 tiles x split-K 4 measured no better than 128x128 tiles without / with split-K 3 (profiles/r03_vith_gemm_t160.txt).
+static bool use_tile160(const GemmParams& p) {
+    static const bool on = !(getenv("SRH_GEMM_T160") && atoi(getenv("SRH_GEMM_T160")) == 0);
+    if (!on || p.conv_S > 0 || p.pos || p.N % 160 != 0 || p.N % 128 != 0 || p.K % BK != 0 || p.M >= 4096) return false;
+    const long t128 = (long)((p.M + 127) / 128) * (p.N / 128), t160 = (long)((p.M + 127) / 128) * (p.N / 160);
+    return t128 > 512 && t160 <= 512;
+}
+
 // Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
 int gemm_splitk_factor(const GemmParams& p) {
     static const bool on = !(getenv("SRH_GEMM_SPLITK") && atoi(getenv("SRH_GEMM_SPLITK")) == 0);
     if (!on || p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
     if (p.M >= 4096 || q192_preferred(p)) return 1;
+    if (use_tile160(p)) return 1;
     const long tiles = (long)(p.M / 128) * (p.N / 128);
     const int nk = p.K / BK;
     if (tiles >= 224 || nk < 16) return 1;
@@ -540,6 +639,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds160_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -560,9 +660,24 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         else hipLaunchKernelGGL(gemm_glds256_kernel<0>, g256, dim3(512), 131072, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
+    const bool t160 = variant == 0 && use_tile160(p);
+    const int want160 = t160 ? gemm_splitk_factor(p) : 1;      // 1, or 4 when the 160-wide tiles only fill the chip with split-K
+    if ((t160 && (want160 == 1 || (p.split_ws && p.splitk == want160))) || variant == 30 || variant == 31) {
+        // variant 30 / 31 (probe): force the 160-wide tiles without / with split-K (31 needs p.split_ws and p.splitk)
+        const int sk = p.split_ws && p.splitk > 1 && variant != 30 ? p.splitk : 1;
+        if (p.N % 160 != 0) return -2;
+        GemmParams q = p;
+        q.splitk = sk;
+        hipLaunchKernelGGL(gemm_glds160_kernel, dim3(((p.M + 127) / 128) * (p.N / 160), sk), dim3(256), 73728, stream, q);
+        if (sk > 1) {
+            const size_t quads = (size_t)p.M * p.N / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, q);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);
     if (variant == 0 && p.split_ws && p.splitk > 1) {
-        if (p.splitk != gemm_splitk_factor(p)) return -2;
+        if (p.splitk != gemm_splitk_factor(p) || p.splitk > (p.K / BK)) return -2;
         hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid, p.splitk), dim3(256), 65536, stream, p);
         const size_t quads = (size_t)p.M * p.N / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);

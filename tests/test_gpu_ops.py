@@ -28,7 +28,10 @@ def _sync():
 @pytest.mark.parametrize("M,N,K,act,resid", [(256, 128, 64, 0, False), (300, 256, 192, 1, False),
                                               (1000, 768, 768, 0, True), (128, 384, 3072, 2, False),
                                               # small-M layers of ViT-H at 256 px: the deterministic split-K path (3 / 4 K-slices)
-                                              (2048, 1280, 5120, 0, True), (2048, 1280, 1280, 1, False), (256, 768, 3072, 0, True)])
+                                              (2048, 1280, 5120, 0, True), (2048, 1280, 1280, 1, False), (256, 768, 3072, 0, True),
+                                              # ViT-H fc1 at M = 2048: 640 tiles of 128x128 -> the 128x160 kernel (512 tiles, one round);
+                                              # with a ragged M (1990 rows: the last tile row is partly empty) and with a residual
+                                              (2048, 5120, 320, 1, False), (1990, 5120, 192, 0, True)])
 def test_gemm(ctx, M, N, K, act, resid):
     g = torch.Generator().manual_seed(M + N + K)
     A = (torch.randn(M, K, generator=g) * 0.5).half()

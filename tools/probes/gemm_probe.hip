@@ -77,12 +77,17 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(db, hb.data(), s.N * 4, hipMemcpyHostToDevice));
         naive_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(dA, dW, db, dR, s.M, s.N, s.K, s.act, ref, LDA, LDW);
         CK(hipDeviceSynchronize());
+        float* ws = nullptr;                                   // split-K workspace: 4 slices of f32 partials
+        CK(hipMalloc(&ws, nO * 4 * 4));
         auto make = [&](int variant) {
             GemmParams g;
             g.A = dA; g.lda = LDA; g.W = dW; g.ldw = LDW; g.M = s.M; g.N = s.N; g.K = s.K; g.bias = db;
             g.resid = dR; g.ldr = s.N; g.act = s.act; g.variant = variant;
             if (s.f16out) { g.out_f16 = o16; g.ldc16 = s.N; } else { g.out_f32 = o32; g.ldc = s.N; }
             g.dbg = ddbg;
+            // variant 0 = what the library would do: split-K where its heuristic asks for it; 31 = 128x160 tiles with split-K 4
+            if (variant == 0) { GemmParams t = g; t.variant = 0; const int sk = gemm_splitk_factor(t); if (sk > 1) { g.splitk = sk; g.split_ws = ws; } }
+            if (variant == 31) { g.splitk = 4; g.split_ws = ws; }
             return g;
         };
         std::vector<std::vector<float>> times(variants.size());
@@ -124,7 +129,7 @@ int main(int argc, char** argv) {
             printf("%-5s M=%d N=%d K=%d variant %3d: median %8.1f us (%7.1f TFLOP/s)   min %8.1f us (%7.1f)\n", s.name, s.M, s.N, s.K,
                    variants[vi], med * 1e3, fl / med / 1e9, mn * 1e3, fl / mn / 1e9);
         }
-        for (void* q : {(void*)dA, (void*)dW, (void*)db, (void*)o16, (void*)o32, (void*)ref, (void*)dmax, (void*)dR}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)dA, (void*)dW, (void*)db, (void*)o16, (void*)o32, (void*)ref, (void*)dmax, (void*)dR, (void*)ws}) if (q) (void)hipFree(q);
     }
     return 0;
 }

@@ -21,7 +21,7 @@ def mean_by_kernel(path, counter):
     for f in glob.glob(os.path.join(path, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"][:r["Kernel_Name"].rfind("(")].replace("void ", "")].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 

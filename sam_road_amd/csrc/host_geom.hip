@@ -141,7 +141,59 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
     if (n < 0 || n_tiles < 0 || K <= 0 || radius < 0 || (n_tiles > 0 && (!boxes || !offsets || !ids || !knn || !ambiguous)))
         return SRH_ERR_BAD_ARG;
     const int64_t r2 = radius * radius;
+    // ---- once per scene: every point's K+1 nearest OTHER points among ALL points (distance < radius, ascending by (distance,
+    // index)) and whether its answer is ambiguous.  The tilings overlap heavily (a CityScale point lies in ~18 tiles) and for a
+    // point at least `radius` away from all four edges of a tile every such neighbour is inside the tile too: its row in that
+    // tile is the global answer re-indexed — order included, because a tile lists its points by ascending global index.
+    // (Ambiguous points still get the per-tile kd-tree treatment below: the tie is broken by the TILE's tree.)
+    std::vector<int32_t> gknn((size_t)n * K, -1);
+    std::vector<uint8_t> gamb((size_t)n, 0);
+    bool have_global = false;
+    if (n > 0 && n < ((int64_t)1 << 30) && radius > 0) {
+        int64_t minx = pts[0], maxx = pts[0], miny = pts[1], maxy = pts[1];
+        for (int64_t i = 1; i < n; ++i) {
+            minx = std::min(minx, pts[2 * i]); maxx = std::max(maxx, pts[2 * i]);
+            miny = std::min(miny, pts[2 * i + 1]); maxy = std::max(maxy, pts[2 * i + 1]);
+        }
+        const int64_t gw = (maxx - minx) / radius + 1, gh = (maxy - miny) / radius + 1;
+        if (gw * gh <= ((int64_t)1 << 24)) {
+            std::vector<int32_t> cs((size_t)(gw * gh) + 1, 0), pc((size_t)n), order((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                pc[(size_t)i] = (int32_t)(((pts[2 * i + 1] - miny) / radius) * gw + (pts[2 * i] - minx) / radius);
+                ++cs[(size_t)pc[(size_t)i] + 1];
+            }
+            for (size_t c = 0; c < (size_t)(gw * gh); ++c) cs[c + 1] += cs[c];
+            std::vector<int32_t> fill(cs.begin(), cs.end() - 1);
+            for (int64_t i = 0; i < n; ++i) order[(size_t)fill[(size_t)pc[(size_t)i]]++] = (int32_t)i;
+            std::vector<std::pair<int64_t, int32_t>> cand;
+            for (int64_t i = 0; i < n; ++i) {
+                cand.clear();
+                const int64_t cx = pc[(size_t)i] % gw, cy = pc[(size_t)i] / gw;
+                for (int64_t yy = std::max<int64_t>(cy - 1, 0); yy <= std::min<int64_t>(cy + 1, gh - 1); ++yy)
+                    for (int64_t xx = std::max<int64_t>(cx - 1, 0); xx <= std::min<int64_t>(cx + 1, gw - 1); ++xx)
+                        for (int32_t q = cs[(size_t)(yy * gw + xx)]; q < cs[(size_t)(yy * gw + xx) + 1]; ++q) {
+                            const int32_t j = order[(size_t)q];
+                            if (j == i) continue;
+                            const int64_t dx = pts[2 * j] - pts[2 * i], dy = pts[2 * j + 1] - pts[2 * i + 1], d2 = dx * dx + dy * dy;
+                            if (d2 < r2) cand.emplace_back(d2, j);
+                        }
+                bool amb = false;
+                const size_t keep = std::min<size_t>((size_t)K, cand.size());
+                if (cand.size() > (size_t)K) {
+                    std::partial_sort(cand.begin(), cand.begin() + K + 1, cand.end());
+                    amb |= cand[(size_t)K].first == cand[(size_t)K - 1].first;
+                } else {
+                    std::sort(cand.begin(), cand.end());
+                }
+                amb |= !cand.empty() && cand[0].first == 0;
+                for (size_t q = 0; q < keep; ++q) gknn[(size_t)i * K + q] = cand[q].second;
+                gamb[(size_t)i] = amb ? 1 : 0;
+            }
+            have_global = true;
+        }
+    }
     auto work = [&](int32_t t_begin, int32_t t_end) {
+        std::vector<int32_t> gmap(have_global ? (size_t)n : 0, -1);     // global point index -> row in the current tile
         std::vector<int64_t> lx, ly;
         std::vector<std::pair<int64_t, int32_t>> cand;
         std::vector<int32_t> cstart, cfill, pcell, corder, res;
@@ -173,8 +225,18 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
             corder.resize((size_t)m);
             cfill.assign(cstart.begin(), cstart.end() - 1);
             for (int32_t i = 0; i < m; ++i) corder[(size_t)cfill[(size_t)pcell[(size_t)i]]++] = i;
+            if (have_global) for (int32_t i = 0; i < m; ++i) gmap[(size_t)tid[i]] = i;
             for (int32_t i = 0; i < m; ++i) {
                 bool amb = false;
+                if (have_global && lx[i] - x0 >= radius && x1 - lx[i] >= radius && ly[i] - y0 >= radius && y1 - ly[i] >= radius) {
+                    // interior point: the global answer, re-indexed (every neighbour is inside the closed box)
+                    const int32_t* gk = gknn.data() + (size_t)tid[i] * K;
+                    for (int32_t q = 0; q < K; ++q) tk[(size_t)i * K + q] = gk[q] >= 0 ? gmap[(size_t)gk[q]] : -1;
+                    amb = gamb[(size_t)tid[i]] != 0;
+                    tamb[i] = amb ? 1 : 0;
+                    any_amb |= amb;
+                    continue;
+                }
                 cand.clear();
                 const int32_t cx = pcell[(size_t)i] % gw, cy = pcell[(size_t)i] / gw;
                 for (int32_t yy = std::max(cy - 1, 0); yy <= std::min(cy + 1, gh - 1); ++yy)
@@ -210,6 +272,7 @@ extern "C" int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxe
                     for (int32_t q = 0; q < K; ++q) tk[(size_t)i * K + q] = res[(size_t)q + 1] < m ? res[(size_t)q + 1] : -1;
                 }
             }
+            if (have_global) for (int32_t i = 0; i < m; ++i) gmap[(size_t)tid[i]] = -1;
         }
     };
     const int32_t nt = std::max<int32_t>(1, std::min<int32_t>(n_threads, n_tiles));

@@ -23,7 +23,8 @@ PARITY UNPINNED (by the reference's own tests)
 * The oracle is therefore anchored on what *is* available:
     - the encoder restatement is cross-checked against the independent
       ``transformers.models.sam.modeling_sam.SamVisionEncoder`` (installed,
-      eager attention) — ``tests/test_oracle_encoder_vs_hf.py``;
+      eager attention) — ``tests/test_oracle_golden.py`` (``test_encoder_matches_hf_golden``,
+      ``test_encoder_matches_hf_at_true_vitb_512_dims``);
     - ``BilinearSampler`` / ``TopoNet`` / ``get_patch_info_one_img`` /
       ``nms_points`` are checked against golden vectors produced by executing
       the reference's *own source* for those definitions (extracted by AST from

@@ -244,3 +244,31 @@ def test_packed_weights_export_import_roundtrip():
         next(other.parameters()).add_(1.0)
     with pytest.raises(_lib.SrhError):
         other.infer_masks_and_img_features(rgb)
+
+
+def test_packed_weights_through_rccl_broadcast():
+    """The collective itself on the GPU box (one rank: gpurun exposes one GPU): a process group on backend nccl (= RCCL), the
+    packed arena of a model through distributed.broadcast_bytes exactly as SAMRoad.share_packed_weights sends it, imported into
+    a second model — same outputs bit for bit.  (World sizes > 1: the same code under gloo in tests/test_distributed_cpu.py.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from sam_road_amd import Config, SAMRoad
+    from sam_road_amd import distributed as D
+    cfg = CFG256 | dict(ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[])
+    _, net = build_pair(cfg)
+    rgb = synth_tiles(1, 256, seed=2).cuda()
+    want = net.infer_masks_and_img_features(rgb)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        buf = D.broadcast_bytes(net.export_packed(torch.device("cuda", 0)), src=0, device=torch.device("cuda", 0))
+        net.share_packed_weights(src=0)                   # world size 1: a no-op by definition
+    finally:
+        dist.destroy_process_group()
+    other = SAMRoad(Config(cfg))
+    other.eval().to("cuda")
+    other.import_packed(buf)
+    got = other.infer_masks_and_img_features(rgb)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 3
+#define SRH_ABI_VERSION 4
 
 typedef enum {
     SRH_OK = 0,
@@ -173,10 +173,11 @@ int srh_nms_points_host(const int32_t* xy, const uint8_t* force, int64_t n, int3
  * equidistant, or a point coinciding with the source — the row is decided exactly as `scipy.spatial.KDTree(tile points)
  * .query(p, k = K+1, distance_upper_bound = radius)[1:]` decides it (same kd-tree, traversal and heaps restated in
  * csrc/kdtree_emul.hpp; scipy 1.15) and comes in scipy's output order; ambiguous [total] marks those rows (information
- * only: nothing is left for the caller to recompute). */
+ * only: nothing is left for the caller to recompute); local (nullable) int64 [total,2] receives every row's tile-local (x, y) =
+ * point - (x0, y0), the coordinates TopoNet samples at (inferencer.py:151). */
 int srh_pass2_count(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int64_t* counts);
 int srh_pass2_fill(const int64_t* pts, int64_t n, const int32_t* boxes, int32_t n_tiles, int32_t K, int64_t radius,
-                   const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int32_t n_threads);
+                   const int64_t* offsets, int64_t* ids, int32_t* knn, uint8_t* ambiguous, int64_t* local, int32_t n_threads);
 
 /* `scipy.spatial.KDTree(points, leafsize).query(queries, k, distance_upper_bound=r)` (the reference's kNN, inferencer.py:156-160)
  * restated for 2-D points, INCLUDING how scipy breaks ties between equidistant points: points f64 [n,2], queries f64 [nq,2] ->
@@ -186,10 +187,19 @@ int srh_kdtree_knn_host(const double* points, int64_t n, int32_t leafsize, const
                         double distance_upper_bound, int32_t* out_idx, int32_t* tree_indices);
 
 /* Candidate pixels of a fused u8 mask: reference graph_extraction.py:24-28 (`np.where(mask > threshold)` and the scores
- * there), row-major order.  Call with xy = scores = NULL to get *n, then again with xy int64 [n,2] (x, y) and scores u8 [n]
- * (capacity = n). */
+ * there), row-major order.  xy int64 [capacity,2] (x, y) and scores u8 [capacity] receive the candidates and *n their number;
+ * if capacity is too small (or xy = scores = NULL) only *n is written (SRH_ERR_BAD_ARG in the former case): call again with
+ * capacity >= *n.  n_threads worker threads scan bands of rows (count, prefix, write). */
 int srh_mask_candidates(const uint8_t* mask, int32_t H, int32_t W, float threshold, int64_t* xy, uint8_t* scores,
-                        int64_t capacity, int64_t* n);
+                        int64_t capacity, int64_t* n, int32_t n_threads);
+
+/* The last of the three nms_points calls of graph_extraction.py:130-139 together with the gathers in front of it: candidates =
+ * [xy_a[ord_a]; xy_b[ord_b]] (keypoint, then road candidates, each in its np.argsort(scores)[::-1] order), visited in `order`
+ * (np.argsort of the priorities [1]*na + [0]*nb, reversed — computed by the caller with numpy so that the tie order is the
+ * reference's), no candidate forced; greedy radius suppression as srh_nms_points_host.  out_xy int64 [na+nb,2] receives the kept
+ * points (x, y) in visiting order, *n_out their number. */
+int srh_nms_merge_points(const int64_t* xy_a, const int64_t* ord_a, int64_t na, const int64_t* xy_b, const int64_t* ord_b, int64_t nb,
+                         const int64_t* order, int32_t radius, int64_t* out_xy, int64_t* n_out);
 
 /* Votes of one TopoNet batch in the reference's visiting order (inferencer.py:206-221: tile, source point, neighbour slot):
  * scores [nb, n_max, K] f32 host (NaN already replaced by -100), offsets [nb+1] rows of these tiles in ids / knn (the
@@ -215,6 +225,24 @@ int srh_edge_vote_accumulate(const int64_t* keys, const double* scores, int64_t 
  * partition pass), each sorted and accumulated by its own thread; identical outputs, bit for bit. */
 int srh_edge_vote_accumulate_mt(const int64_t* keys, const double* scores, int64_t n, int64_t* out_keys, double* out_sums,
                                 double* out_counts, int64_t* out_first, int64_t* n_unique, int32_t n_threads);
+
+/* srh_pass2_votes + srh_edge_vote_accumulate in one pass over the query rows, without materialising the votes (reference
+ * inferencer.py:206-228).  scores[b] = f32 [batch_nb[b], batch_n_max[b], K] host scores (NaN -> -100 done) of the tiles
+ * batch_tile0[b] .. batch_tile0[b] + batch_nb[b] (indices into offsets [n_tiles+1]; ids / knn = the srh_pass2_fill layout; a tile
+ * outside every batch must be empty).  Rows are grouped by source point and each point's votes are added, in the reference's
+ * visiting order, into a table of its targets: same unique keys (ascending), float64 sums, counts and first-vote positions as the
+ * two-call path, bit for bit.  capacity = number of non-negative knn entries always suffices.  SRH_ERR_BAD_ARG if a valid pair's
+ * score is outside [0, 1] (the reference's assert, inferencer.py:219). */
+int srh_pass2_vote_sums(const float* const* scores, const int32_t* batch_tile0, const int32_t* batch_nb, const int64_t* batch_n_max,
+                        int32_t n_batches, int32_t K, const int64_t* offsets, int32_t n_tiles, const int64_t* ids, const int32_t* knn,
+                        int64_t n_points, int64_t* out_keys, double* out_sums, double* out_counts, int64_t* out_first,
+                        int64_t capacity, int64_t* n_unique, int32_t n_threads);
+
+/* Edge list from the vote sums (reference inferencer.py:224-228): the (src, tgt) pairs whose mean score sums / max(counts, 1)
+ * exceeds the threshold, in the insertion order of the reference's dict (ascending first-vote position; `first` values are
+ * distinct).  out_edges int64 [n,2]; *n_edges their number. */
+int srh_votes_to_edges(const int64_t* keys, const double* sums, const double* counts, const int64_t* first, int64_t n,
+                       int64_t n_points, double threshold, int64_t* out_edges, int64_t* n_edges);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRH_LIB_PATH") or os.path.join(_HERE, "libsamroad_hip.so")
 
 SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SrhError(RuntimeError):
@@ -56,11 +56,14 @@ SYMBOLS = {
     "srh_op_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "srh_nms_points_host": (_I, [_P, _P, C.c_int64, C.c_int32, _P]),
     "srh_pass2_count": (_I, [_P, C.c_int64, _P, C.c_int32, _P]),
-    "srh_pass2_fill": (_I, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32]),
+    "srh_pass2_fill": (_I, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, C.c_int32]),
     "srh_pass2_votes": (_I, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),
+    "srh_pass2_vote_sums": (_I, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, _P, C.c_int32]),
+    "srh_votes_to_edges": (_I, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, _P, _P]),
     "srh_pass2_pack": (_I, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     "srh_kdtree_knn_host": (_I, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_double, _P, _P]),
-    "srh_mask_candidates": (_I, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int64, _P]),
+    "srh_mask_candidates": (_I, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int64, _P, C.c_int32]),
+    "srh_nms_merge_points": (_I, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int32, _P, _P]),
     "srh_edge_vote_accumulate": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "srh_edge_vote_accumulate_mt": (_I, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32]),
     "srh_profile_enable": (_I, [_P, _I]),

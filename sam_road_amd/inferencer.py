@@ -19,7 +19,7 @@ import torch
 
 from . import distributed as D
 from .graph_points import extract_graph_points
-from .hostcpu import usable_cpus, worker_threads
+from .hostcpu import fill_threads, usable_cpus, worker_threads
 from .tiling import get_patch_info_one_img, shard_tiles
 
 
@@ -95,16 +95,14 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     offsets = np.zeros(n_tiles + 1, dtype=np.int64)
     np.cumsum(counts, out=offsets[1:])
     total = int(offsets[-1])
-    ids = np.zeros(total, dtype=np.int64)
-    knn = np.zeros((total, k), dtype=np.int32)
-    amb = np.zeros(total, dtype=np.uint8)
-    if lib.srh_pass2_fill(vp(pts), pts.shape[0], vp(boxes), n_tiles, k, int(r), vp(offsets), vp(ids), vp(knn), vp(amb),
-                          worker_threads()) != 0:
+    ids = np.empty(total, dtype=np.int64)                     # srh_pass2_fill writes every element of the four arrays
+    knn = np.empty((total, k), dtype=np.int32)
+    amb = np.empty(total, dtype=np.uint8)
+    local = np.empty((total, 2), dtype=np.int64)
+    if lib.srh_pass2_fill(vp(pts), pts.shape[0], vp(boxes), n_tiles, k, int(r), vp(offsets), vp(ids), vp(knn), vp(amb), vp(local),
+                          fill_threads()) != 0:
         raise _lib.SrhError("srh_pass2_fill failed")
     lap("count + fill (library)")
-    tile_of = np.repeat(np.arange(n_tiles), counts)
-    local = pts[ids] - boxes[tile_of, :2].astype(np.int64)
-    lap("numpy post")
     # (source points whose answer is not determined by distances alone — a tie at the K-th neighbour, a coincident point — were
     # decided inside the library the way the reference's scipy kd-tree decides them, csrc/kdtree_emul.hpp; round 2 re-queried
     # scipy per tile here: 11.5 ms per CityScale scene)
@@ -187,6 +185,34 @@ def _votes_from_scores(fq, lo, batches, n_pts, K):
     return k[:cnt_c.value], s[:cnt_c.value]
 
 
+def _vote_sums(fq, lo, batches, n_pts, K):
+    """_votes_from_scores + _accumulate_votes without the ~700k intermediate votes of a CityScale scene: the library groups the
+    query rows by source point and adds every point's votes into a table of its few dozen targets (srh_pass2_vote_sums,
+    csrc/host_geom.hip; visiting order per key kept, so the float64 sums, counts and first-vote positions are the same, bit for
+    bit — tests/test_host_logic.py).  batches = [(off, end, scores f32 [nb,n_max,K] on the host)]."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    keep = [np.ascontiguousarray(sc, dtype=np.float32) for _, _, sc in batches]
+    nb = len(batches)
+    ptrs = (C.c_void_p * max(nb, 1))(*[x.ctypes.data for x in keep])
+    tile0 = np.array([off - lo for off, _, _ in batches], dtype=np.int32)
+    cnt = np.array([end - off for off, end, _ in batches], dtype=np.int32)
+    n_max = np.array([x.shape[1] for x in keep], dtype=np.int64)
+    for x, (off, end, _) in zip(keep, batches):
+        if x.ndim != 3 or x.shape[0] != end - off or x.shape[2] != K:
+            raise ValueError("score batch of the wrong shape")
+    cap = int(fq.knn.size)                     # >= the number of distinct edges; the pages beyond them are never touched
+    uk, sums, cnts, first = np.empty(cap, np.int64), np.empty(cap, np.float64), np.empty(cap, np.float64), np.empty(cap, np.int64)
+    nu = C.c_int64(0)
+    rc = lib.srh_pass2_vote_sums(ptrs, vp(tile0), vp(cnt), vp(n_max), nb, K, vp(fq.offsets), fq.n_tiles, vp(fq.ids), vp(fq.knn),
+                                 n_pts, vp(uk), vp(sums), vp(cnts), vp(first), cap, C.byref(nu), worker_threads())
+    if rc != 0:
+        raise AssertionError("edge score outside [0, 1] (reference inferencer.py:219) or inconsistent query arrays")
+    return uk[:nu.value], sums[:nu.value], cnts[:nu.value], first[:nu.value]
+
+
 def _accumulate_votes(k, s):
     """The reference's dict accumulation (float64 sums in visiting order) as a stable radix sort by key + one sequential pass
     in the library's host code (np.unique + np.bincount did the same in 11 ms per CityScale scene)."""
@@ -252,7 +278,12 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=False)
     if not launched:
         return empty
     if fq is not None:
-        k, s = _votes_from_scores(fq, lo, [(off, end, sc.cpu().numpy()) for off, end, _, sc in launched], n_pts, K)
+        host_scores = [(off, end, sc.cpu().numpy()) for off, end, _, sc in launched]
+        if not raw:
+            out = _vote_sums(fq, lo, host_scores, n_pts, K)
+            lap("score fetch + vote sums")
+            return out
+        k, s = _votes_from_scores(fq, lo, host_scores, n_pts, K)
     else:
         keys_l, score_l = [], []
         for off, end, qs, scores_dev in launched:
@@ -285,9 +316,22 @@ def votes_to_edges(uk, sums, cnts, first, n_pts, threshold):
     per-tile point order, which in the reference is whatever rtree.intersection yields; here tiles list their points by
     ascending global index (the edge SET does not depend on it — pinned by tests/test_refrun_golden.py).  Among EQUIDISTANT
     neighbours of one source point the slot order is scipy-heap-internal in the reference and distance-then-index here."""
-    keep = (sums / np.maximum(cnts, 1.0)) > threshold
-    k = uk[keep][np.argsort(first[keep], kind="stable")]
-    return np.stack([k // n_pts, k % n_pts], axis=1).reshape(-1, 2)
+    n = int(uk.shape[0])
+    arrs = [np.ascontiguousarray(a, dtype=d) for a, d in ((uk, np.int64), (sums, np.float64), (cnts, np.float64), (first, np.int64))]
+    if n == 0 or n_pts <= 0 or any(a.shape != (n,) for a in arrs):
+        keep = (sums / np.maximum(cnts, 1.0)) > threshold
+        k = uk[keep][np.argsort(first[keep], kind="stable")]
+        return np.stack([k // n_pts, k % n_pts], axis=1).reshape(-1, 2)
+    import ctypes as C
+    from . import _lib
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = np.empty((n, 2), dtype=np.int64)
+    ne = C.c_int64(0)
+    # library host code (srh_votes_to_edges): the kept edges dropped into a table indexed by first-vote position, read back in order
+    rc = _lib.load().srh_votes_to_edges(*(vp(a) for a in arrs), n, int(n_pts), float(threshold), vp(out), C.byref(ne))
+    if rc != 0:
+        raise _lib.SrhError(f"srh_votes_to_edges failed ({rc})")
+    return out[:ne.value].copy()
 
 
 def _numpy_hugepages(enabled):
@@ -576,9 +620,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
                 t = job.t
                 print(f"[infer_imgs] device: pass 1 {t[0].elapsed_time(t[1]):.1f} ms, mask download -> pass 2 start {t[1].elapsed_time(t[2]):.1f} ms, "
                       f"pass 2 {t[2].elapsed_time(t[3]):.1f} ms, score download {t[3].elapsed_time(t[4]):.1f} ms", flush=True)
-            k, s = _votes_from_scores(job.fq, 0, [(off, end, sc.numpy()) for (off, end, _, _), sc in zip(job.plan, job.scores)],
-                                      n_pts, K)
-            job.votes = _accumulate_votes(k, s)
+            job.votes = _vote_sums(job.fq, 0, [(off, end, sc.numpy()) for (off, end, _, _), sc in zip(job.plan, job.scores)], n_pts, K)
         edges = votes_to_edges(*job.votes, n_pts, config.TOPO_THRESHOLD)
         lap("votes -> edges")
         return nodes, edges, job.kp_mask, job.road_mask

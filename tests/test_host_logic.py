@@ -457,3 +457,146 @@ def test_pass2_pack_matches_per_tile_collate():
         np.testing.assert_array_equal(p_h[sl].reshape(end - off, n_max, 2), inf._collate([t[1].astype(np.float32) for t in tiles]))
         np.testing.assert_array_equal(q_h[sl].reshape(end - off, n_max, K, 2), inf._collate([t[2].astype(np.int32) for t in tiles]))
         np.testing.assert_array_equal(v_h[sl].reshape(end - off, n_max, K), inf._collate([t[3].astype(np.uint8) for t in tiles]))
+
+
+def test_pass2_vote_sums_equal_reference_dicts():
+    """srh_pass2_vote_sums (rows grouped by source point, a table of targets per point) == the reference's dicts filled by the
+    triple loop (inferencer.py:206-228): keys, float64 sums in visiting order, counts and insertion positions, bit for bit; any
+    thread count; several batches with different paddings; an out-of-range score is refused."""
+    from collections import OrderedDict
+    from sam_road_amd import inferencer as inf
+    rng = np.random.default_rng(8)
+    pts = np.unique(rng.integers(0, 420, size=(900, 2)), axis=0).astype(np.int64)
+    cfg = Config(NEIGHBOR_RADIUS=40, MAX_NEIGHBOR_QUERIES=16)
+    infos = get_patch_info_one_img(0, 448, 0, 128, 6)
+    fq = inf.build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+    K, n_pts, n_tiles = 16, pts.shape[0], len(infos)
+    batches, bs = [], 7
+    for off in range(0, n_tiles, bs):
+        end = min(off + bs, n_tiles)
+        n_max = int(np.diff(fq.offsets[off:end + 1]).max()) + (off % 3)
+        if n_max:
+            batches.append((off, end, rng.random((end - off, n_max, K)).astype(np.float32)))
+    sums, cnts = OrderedDict(), OrderedDict()
+    for off, end, sc in batches:                                  # the reference's loop
+        for b in range(end - off):
+            ids, _, pairs, valid = fq.tile(off + b)
+            for si in range(len(ids)):
+                for pi in range(K):
+                    if valid[si, pi]:
+                        key = int(ids[pairs[si, pi, 0]]) * n_pts + int(ids[pairs[si, pi, 1]])
+                        sums[key] = sums.get(key, 0.0) + float(sc[b, si, pi])
+                        cnts[key] = cnts.get(key, 0.0) + 1.0
+    assert len(sums) > 1000
+    old = inf._accumulate_votes(*inf._votes_from_scores(fq, 0, batches, n_pts, K))
+    wt = inf.worker_threads
+    try:
+        for nt in (1, 2, 5):
+            inf.worker_threads = lambda: nt
+            uk, su, cn, fi = inf._vote_sums(fq, 0, batches, n_pts, K)
+            assert uk.tolist() == sorted(sums)
+            assert su.tolist() == [sums[k] for k in uk.tolist()] and cn.tolist() == [cnts[k] for k in uk.tolist()]
+            assert uk[np.argsort(fi)].tolist() == list(sums)      # first-vote positions = the dict's insertion order
+            for a, b in zip((uk, su, cn, fi), old):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        inf.worker_threads = wt
+    off, end, sc = batches[1]
+    a = int(fq.offsets[off])
+    j = int(np.argmax(fq.knn[a] >= 0))
+    bad = sc.copy(); bad[0, 0, j] = 1.25
+    with pytest.raises(AssertionError):
+        inf._vote_sums(fq, 0, [batches[0], (off, end, bad)] + batches[2:], n_pts, K)
+    # a non-empty tile that no batch covers is an inconsistency, not a silent loss of votes
+    with pytest.raises(AssertionError):
+        inf._vote_sums(fq, 0, batches[1:], n_pts, K)
+
+
+def test_mask_candidates_threads_and_capacity():
+    """srh_mask_candidates with worker threads (bands of rows) == np.where order for every thread count, and the single-call
+    protocol: a too small capacity reports the needed one."""
+    import ctypes as C
+    from sam_road_amd.graph_points import points_and_scores_from_mask
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    m = (rng.random((700, 333)) ** 6 * 255).astype(np.uint8)
+    m[100:180] = 0                                                # bands without a candidate
+    sel = m > 100.5
+    want_xy, want_sc = np.column_stack(np.where(sel))[:, ::-1], m[sel]
+    for nt in (1, 2, 3, 8, 64):
+        xy, sc = points_and_scores_from_mask(m, 100.5, nt)
+        np.testing.assert_array_equal(xy, want_xy)
+        np.testing.assert_array_equal(sc, want_sc)
+    n = C.c_int64(0)
+    xy, sc = np.empty((10, 2), np.int64), np.empty(10, np.uint8)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.srh_mask_candidates(vp(m), 700, 333, 100.5, vp(xy), vp(sc), 10, C.byref(n), 4) != 0 and n.value == len(want_sc)
+    assert lib.srh_mask_candidates(vp(m), 700, 333, 100.5, None, None, 0, C.byref(n), 4) == 0 and n.value == len(want_sc)
+
+
+def test_extract_graph_points_fast_path_equals_general_path():
+    """The u8 fast path of extract_graph_points (threaded scans + one srh_nms_merge_points call) returns exactly what the three
+    nms_points calls of graph_extraction.py:130-139 return (general path, forced here with non-contiguous masks)."""
+    from oracle import scene as oscene
+    from oracle.samroad import AttrDict
+    rng = np.random.default_rng(21)
+    for size, pk, pr in ((384, 8, 4), (640, 12, 6)):
+        kp2 = (rng.random((size, 2 * size)) ** pk * 255).astype(np.uint8)
+        road2 = (rng.random((size, 2 * size)) ** pr * 255).astype(np.uint8)
+        kp_nc, road_nc = kp2[:, ::2], road2[:, ::2]               # same pixels, not C-contiguous -> general path
+        kp, road = np.ascontiguousarray(kp_nc), np.ascontiguousarray(road_nc)
+        cfg = Config(ITSC_THRESHOLD=0.4, ROAD_THRESHOLD=0.5, ITSC_NMS_RADIUS=8, ROAD_NMS_RADIUS=16)
+        fast = extract_graph_points(kp, road, cfg)
+        np.testing.assert_array_equal(fast, extract_graph_points(kp_nc, road_nc, cfg))
+        np.testing.assert_array_equal(fast, oscene.extract_graph_points(kp, road, AttrDict(cfg)))
+        assert fast.dtype == np.int64 and fast.flags.c_contiguous and len(fast) > 50
+    empty = np.zeros((128, 128), np.uint8)
+    assert extract_graph_points(empty, empty, cfg).shape == (0, 2)
+    np.testing.assert_array_equal(extract_graph_points(empty, road[:128, :128].copy(), cfg),
+                                  extract_graph_points(empty[:, ::1][::1, :], np.asfortranarray(road[:128, :128]), cfg))
+
+
+def test_pass2_fill_local_coordinates_and_thread_counts():
+    """srh_pass2_fill's `local` output = point - tile origin (inferencer.py:151), and ids / knn / tied flags do not depend on the
+    number of worker threads (shared pre-pass, tiles taken from a counter)."""
+    from sam_road_amd import inferencer as inf
+    rng = np.random.default_rng(2)
+    pts = np.unique(rng.integers(0, 500, size=(1500, 2)), axis=0).astype(np.int64)
+    cfg = Config(NEIGHBOR_RADIUS=48, MAX_NEIGHBOR_QUERIES=16)
+    infos = get_patch_info_one_img(0, 512, 0, 160, 5)
+    wt = inf.fill_threads
+    try:
+        inf.fill_threads = lambda: 1
+        ref = inf.build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+        tile_of = np.repeat(np.arange(len(infos)), np.diff(ref.offsets))
+        origin = np.array([info[1] for info in infos], dtype=np.int64)
+        np.testing.assert_array_equal(ref.local, pts[ref.ids] - origin[tile_of])
+        for nt in (2, 7, 32):
+            inf.fill_threads = lambda: nt
+            fq = inf.build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+            for name in ("offsets", "ids", "local", "knn", "tied"):
+                np.testing.assert_array_equal(getattr(fq, name), getattr(ref, name))
+    finally:
+        inf.fill_threads = wt
+
+
+def test_votes_to_edges_matches_numpy_form():
+    """srh_votes_to_edges == the numpy statement of inferencer.py:224-228 (mean > threshold, insertion order) for dense positions
+    (one process), positions offset per rank (multi-rank merge) and repeated positions (stable order)."""
+    from sam_road_amd.inferencer import votes_to_edges
+    rng = np.random.default_rng(4)
+    def numpy_form(uk, sums, cnts, first, n_pts, thr):
+        keep = (sums / np.maximum(cnts, 1.0)) > thr
+        k = uk[keep][np.argsort(first[keep], kind="stable")]
+        return np.stack([k // n_pts, k % n_pts], axis=1).reshape(-1, 2)
+    n_pts, n = 700, 5000
+    uk = np.sort(rng.choice(n_pts * n_pts, n, replace=False)).astype(np.int64)
+    cnts = rng.integers(0, 6, n).astype(np.float64)
+    sums = rng.random(n) * np.maximum(cnts, 1.0)
+    sums[::7] = 0.499 * np.maximum(cnts[::7], 1.0)                # exactly at / next to the threshold
+    dense = rng.permutation(40000)[:n].astype(np.int64)
+    for first in (dense, dense + (rng.integers(0, 3, n).astype(np.int64) << 40), rng.integers(0, 50, n).astype(np.int64), np.zeros(n, np.int64)):
+        got = votes_to_edges(uk, sums, cnts, first, n_pts, 0.499)
+        np.testing.assert_array_equal(got, numpy_form(uk, sums, cnts, first, n_pts, 0.499))
+        assert got.dtype == np.int64 and got.shape[1] == 2 and 0 < len(got) < n
+    assert votes_to_edges(uk[:0], sums[:0], cnts[:0], dense[:0], n_pts, 0.499).shape == (0, 2)

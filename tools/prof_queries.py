@@ -32,5 +32,5 @@ print("srh_pass2_count ms", T(lambda: lib.srh_pass2_count(vp(pts), len(pts), vp(
 offsets = np.zeros(257, np.int64); np.cumsum(counts, out=offsets[1:]); total = int(offsets[-1])
 ids = np.zeros(total, np.int64); knn = np.zeros((total, 16), np.int32); amb = np.zeros(total, np.uint8)
 for nt in (1, 2, 4, 8, 16):
-    print("srh_pass2_fill threads", nt, "ms", T(lambda: lib.srh_pass2_fill(vp(pts), len(pts), vp(boxes), 256, 16, 64, vp(offsets), vp(ids), vp(knn), vp(amb), nt)))
+    print("srh_pass2_fill threads", nt, "ms", T(lambda: lib.srh_pass2_fill(vp(pts), len(pts), vp(boxes), 256, 16, 64, vp(offsets), vp(ids), vp(knn), vp(amb), None, nt)))
 print("np.zeros of the outputs ms", T(lambda: (np.zeros(total, np.int64), np.zeros((total, 16), np.int32), np.zeros(total, np.uint8))))

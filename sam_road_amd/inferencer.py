@@ -121,67 +121,127 @@ def _collate(xs):
     return out
 
 
-def _pack_pass2_batches(fq, lo, hi, bs, K, alloc=None):
-    """Padded collate (inferencer.py:179-185) of every batch of tiles [lo, hi) into ONE host buffer per kind: returns
-    (plan, points f32 [rows,2], pairs i32 [rows,K,2], valid u8 [rows,K]); plan = [(off, end, n_max, base_row)], batch rows
-    [base, base + (end-off)*n_max).  Indices travel as int32 and the integer pixel coordinates as float32 (exact; srh_toponet
-    accepts both, model.py:47's division promotes anyway).  `alloc(name, shape, dtype)` supplies the arrays (page-locked ones in the
-    pipelined path)."""
+def _sort_pass2_tiles():
+    import os
+    return os.environ.get("SRH_PASS2_SORT", "1") != "0"          # tuning aid: 0 = batches of consecutive tiles, as the reference forms them
+
+
+def _pass2_plan(fq, bs, sort_tiles=None):
+    """Which tiles share a TopoNet batch: [(tiles int64 [nb] — indices into fq —, n_max, base_row)]; a batch is padded to its longest
+    tile (graph_collate_fn-style, inferencer.py:179-185) and owns rows [base, base + nb * n_max) of the staging buffers.
+    The reference batches consecutive tiles, so one dense tile makes 63 others carry its padding: a CityScale-like scene has 48 k
+    query rows and 121 k padded ones.  TopoNet treats every row on its own (the sampler reads the row's tile, the transformer runs
+    over the row's K neighbours), so WHICH tiles share a launch cannot change a score: tiles are grouped by ascending row count
+    instead — 68 k padded rows, a little over half the device time and half the upload / download bytes of pass 2 — and the votes
+    are still read in tile order (the reference's visiting order).  Empty tiles join no batch."""
+    counts = np.diff(fq.offsets)
+    if _sort_pass2_tiles() if sort_tiles is None else sort_tiles:
+        idx = np.flatnonzero(counts > 0)
+        idx = idx[np.argsort(counts[idx], kind="stable")]
+        groups = [idx[i:i + bs] for i in range(0, len(idx), bs)]
+    else:
+        groups = [np.arange(i, min(i + bs, fq.n_tiles)) for i in range(0, fq.n_tiles, bs)]
+    plan, rows_total = [], 0
+    for tiles in groups:
+        n_max = int(counts[tiles].max()) if len(tiles) else 0
+        if n_max:
+            plan.append((tiles.astype(np.int64), n_max, rows_total))
+            rows_total += len(tiles) * n_max
+    return plan, rows_total
+
+
+def _contiguous(tiles):
+    return len(tiles) > 0 and int(tiles[-1]) - int(tiles[0]) == len(tiles) - 1 and bool((np.diff(tiles) == 1).all())
+
+
+def _pack_pass2_batches(fq, lo, hi, bs, K, alloc=None, sort_tiles=None):
+    """Padded collate (inferencer.py:179-185) of every batch of _pass2_plan into ONE host buffer per kind: returns
+    (plan, points f32 [rows,2], pairs i32 [rows,K,2], valid u8 [rows,K]).  Indices travel as int32 and the integer pixel coordinates
+    as float32 (exact; srh_toponet accepts both, model.py:47's division promotes anyway).  `alloc(name, shape, dtype)` supplies the
+    arrays (page-locked ones in the pipelined path).  (lo, hi: the tile range fq was built for; fq indexes tiles from 0.)"""
     if alloc is None:
         alloc = lambda name, shape, dtype: np.zeros(shape, dtype)
-    plan, rows_total = [], 0
-    for off in range(lo, hi, bs):
-        end = min(off + bs, hi)
-        n_max = int(np.diff(fq.offsets[off - lo:end - lo + 1]).max())
-        if n_max:
-            plan.append((off, end, n_max, rows_total))
-            rows_total += (end - off) * n_max
+    plan, rows_total = _pass2_plan(fq, bs, sort_tiles)
     pts_h = alloc("points", (max(rows_total, 1), 2), np.float32)
     pairs_h = alloc("pairs", (max(rows_total, 1), K, 2), np.int32)
     valid_h = alloc("valid", (max(rows_total, 1), K), np.uint8)
-    import ctypes as C
     from . import _lib
     lib = _lib.load()
-    vp = lambda x: x.ctypes.data_as(C.c_void_p)
     local = np.ascontiguousarray(fq.local, dtype=np.int64)
-    for off, end, n_max, base in plan:
-        # library host code (srh_pass2_pack): the numpy scatter of ~90k rows x 16 slots took 4 ms per CityScale scene
-        rows = slice(base, base + (end - off) * n_max)
-        if lib.srh_pass2_pack(vp(fq.offsets[off - lo:]), vp(local), vp(fq.knn), end - off, n_max, K, vp(pts_h[rows]), vp(pairs_h[rows]),
-                              vp(valid_h[rows])) != 0:
-            raise _lib.SrhError("srh_pass2_pack failed")
+    offsets = np.ascontiguousarray(fq.offsets, dtype=np.int64)
+    knn = np.ascontiguousarray(fq.knn, dtype=np.int32)
+    a_off, a_loc, a_knn = offsets.ctypes.data, local.ctypes.data, knn.ctypes.data
+    a_pts, a_pairs, a_valid = pts_h.ctypes.data, pairs_h.ctypes.data, valid_h.ctypes.data
+    for tiles, n_max, base in plan:
+        # library host code (srh_pass2_pack): the numpy scatter of ~90k rows x 16 slots took 4 ms per CityScale scene.  One call per
+        # run of consecutive tiles (raw addresses: a ctypes cast per argument would cost more than a tile's packing)
+        runs = [(0, len(tiles))] if _contiguous(tiles) else [(j, j + 1) for j in range(len(tiles))]
+        for j0, j1 in runs:
+            row = base + j0 * n_max
+            if lib.srh_pass2_pack(a_off + int(tiles[j0]) * 8, a_loc, a_knn, j1 - j0, n_max, K, a_pts + row * 8, a_pairs + row * K * 8,
+                                  a_valid + row * K) != 0:
+                raise _lib.SrhError("srh_pass2_pack failed")
     return plan, pts_h, pairs_h, valid_h
 
 
-def _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, lo):
-    """Sampler + TopoNet (inferencer.py:187-207) for every planned batch; nothing is fetched.  Returns [(off, end, scores)]
-    with scores [nb, n_max, K] on the device (NaN -> -100 as the reference does before its range check)."""
+def _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, lo=0):
+    """Sampler + TopoNet (inferencer.py:187-207) for every planned batch; nothing is fetched.  Returns [(tiles, scores)] with scores
+    [nb, n_max, K] on the device (NaN -> -100 as the reference does before its range check); emb[t] = embeddings of fq's tile t."""
     out = []
-    for off, end, n_max, base in plan:
-        nb, sl = end - off, slice(base, base + (end - off) * n_max)
-        scores = net.infer_toponet(emb[off - lo:end - lo], pts_d[sl].view(nb, n_max, 2), pairs_d[sl].view(nb, n_max, K, 2),
-                                   valid_d[sl].view(nb, n_max, K))
-        out.append((off, end, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
+    for tiles, n_max, base in plan:
+        nb, sl = len(tiles), slice(base, base + len(tiles) * n_max)
+        e = emb[int(tiles[0]):int(tiles[-1]) + 1] if _contiguous(tiles) else emb.index_select(0, torch.as_tensor(tiles, device=emb.device))
+        scores = net.infer_toponet(e, pts_d[sl].view(nb, n_max, 2), pairs_d[sl].view(nb, n_max, K, 2), valid_d[sl].view(nb, n_max, K))
+        out.append((tiles, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
     return out
 
 
+def _tile_slots(fq, lo, batches, K):
+    """Per-tile view of the score batches: [(tile, address of its f32 [n_max, K] block, n_max)] in ascending tile order, plus the
+    arrays that keep the memory alive.  batches = [(tiles, scores [nb,n_max,K])] or, for consecutive tiles, [(off, end, scores)]
+    with absolute tile numbers (off - lo indexes fq)."""
+    keep, slots = [], []
+    for b in batches:
+        if len(b) == 3:
+            tiles, sc = np.arange(b[0] - lo, b[1] - lo, dtype=np.int64), b[2]
+        else:
+            tiles, sc = b
+        sc = np.ascontiguousarray(sc, dtype=np.float32)
+        if sc.ndim != 3 or sc.shape[0] != len(tiles) or sc.shape[2] != K:
+            raise ValueError("score batch of the wrong shape")
+        keep.append(sc)
+        stride = sc.shape[1] * K * 4
+        slots.extend((int(t), sc.ctypes.data + j * stride, sc.shape[1]) for j, t in enumerate(tiles))
+    slots.sort(key=lambda x: x[0])
+    return slots, keep
+
+
 def _votes_from_scores(fq, lo, batches, n_pts, K):
-    """inferencer.py:209-221's visiting order as flat (key, score) vote arrays; batches = [(off, end, scores f32 [nb,n_max,K])]
-    on the host (srh_pass2_votes, csrc/host_geom.hip; it also enforces the reference's 0 <= score <= 1 assertion)."""
+    """inferencer.py:209-221's visiting order (tile, source point, neighbour slot) as flat (key, score) vote arrays; batches as in
+    _tile_slots, on the host (srh_pass2_votes, csrc/host_geom.hip; it also enforces the reference's 0 <= score <= 1 assertion)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    slots, keep = _tile_slots(fq, lo, batches, K)
     cap = int((fq.knn >= 0).sum())
     k = np.empty(cap, np.int64)
     s = np.empty(cap, np.float64)
     cnt_c = C.c_int64(0)
-    for off, end, sc in batches:
-        sc = np.ascontiguousarray(sc, dtype=np.float32)
-        rc = lib.srh_pass2_votes(vp(sc), end - off, sc.shape[1], K, vp(fq.offsets[off - lo:]), vp(fq.ids), vp(fq.knn), n_pts,
-                                 vp(k), vp(s), cap, C.byref(cnt_c))
+    offsets = np.ascontiguousarray(fq.offsets, dtype=np.int64)
+    a_off = offsets.ctypes.data
+    # runs of consecutive tiles that sit one after the other in one score array go through one call
+    i = 0
+    while i < len(slots):
+        t, addr, n_max = slots[i]
+        j = i + 1
+        while j < len(slots) and slots[j][0] == slots[j - 1][0] + 1 and slots[j][2] == n_max and slots[j][1] == slots[j - 1][1] + n_max * K * 4:
+            j += 1
+        rc = lib.srh_pass2_votes(addr, j - i, n_max, K, a_off + t * 8, vp(fq.ids), vp(fq.knn), n_pts, vp(k), vp(s), cap, C.byref(cnt_c))
         if rc != 0:
             raise AssertionError("edge score outside [0, 1] (reference inferencer.py:219) or inconsistent query arrays")
+        i = j
+    del keep
     return k[:cnt_c.value], s[:cnt_c.value]
 
 
@@ -189,25 +249,24 @@ def _vote_sums(fq, lo, batches, n_pts, K):
     """_votes_from_scores + _accumulate_votes without the ~700k intermediate votes of a CityScale scene: the library groups the
     query rows by source point and adds every point's votes into a table of its few dozen targets (srh_pass2_vote_sums,
     csrc/host_geom.hip; visiting order per key kept, so the float64 sums, counts and first-vote positions are the same, bit for
-    bit — tests/test_host_logic.py).  batches = [(off, end, scores f32 [nb,n_max,K] on the host)]."""
+    bit — tests/test_host_logic.py).  batches as in _tile_slots (every tile is handed over as a "batch" of one: where its scores
+    lie does not matter)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    keep = [np.ascontiguousarray(sc, dtype=np.float32) for _, _, sc in batches]
-    nb = len(batches)
-    ptrs = (C.c_void_p * max(nb, 1))(*[x.ctypes.data for x in keep])
-    tile0 = np.array([off - lo for off, _, _ in batches], dtype=np.int32)
-    cnt = np.array([end - off for off, end, _ in batches], dtype=np.int32)
-    n_max = np.array([x.shape[1] for x in keep], dtype=np.int64)
-    for x, (off, end, _) in zip(keep, batches):
-        if x.ndim != 3 or x.shape[0] != end - off or x.shape[2] != K:
-            raise ValueError("score batch of the wrong shape")
+    slots, keep = _tile_slots(fq, lo, batches, K)
+    nb = len(slots)
+    ptrs = (C.c_void_p * max(nb, 1))(*[a for _, a, _ in slots])
+    tile0 = np.array([t for t, _, _ in slots], dtype=np.int32)
+    cnt = np.ones(nb, dtype=np.int32)
+    n_max = np.array([m for _, _, m in slots], dtype=np.int64)
     cap = int(fq.knn.size)                     # >= the number of distinct edges; the pages beyond them are never touched
     uk, sums, cnts, first = np.empty(cap, np.int64), np.empty(cap, np.float64), np.empty(cap, np.float64), np.empty(cap, np.int64)
     nu = C.c_int64(0)
     rc = lib.srh_pass2_vote_sums(ptrs, vp(tile0), vp(cnt), vp(n_max), nb, K, vp(fq.offsets), fq.n_tiles, vp(fq.ids), vp(fq.knn),
                                  n_pts, vp(uk), vp(sums), vp(cnts), vp(first), cap, C.byref(nu), worker_threads())
+    del keep
     if rc != 0:
         raise AssertionError("edge score outside [0, 1] (reference inferencer.py:219) or inconsistent query arrays")
     return uk[:nu.value], sums[:nu.value], cnts[:nu.value], first[:nu.value]
@@ -261,7 +320,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=False)
     if fq is not None:
         plan, pts_h, pairs_h, valid_h = _pack_pass2_batches(fq, lo, hi, bs, K)
         pts_d, pairs_d, valid_d = (torch.from_numpy(x).to(device) for x in (pts_h, pairs_h, valid_h))
-        launched = [(off, end, None, sc) for off, end, sc in _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, lo)]
+        launched = [(tiles, None, None, sc) for tiles, sc in _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K)]
     else:
         for off in range(lo, hi, bs):
             end = min(off + bs, hi)
@@ -278,7 +337,7 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=False)
     if not launched:
         return empty
     if fq is not None:
-        host_scores = [(off, end, sc.cpu().numpy()) for off, end, _, sc in launched]
+        host_scores = [(tiles, sc.cpu().numpy()) for tiles, _, _, sc in launched]
         if not raw:
             out = _vote_sums(fq, lo, host_scores, n_pts, K)
             lap("score fetch + vote sums")
@@ -598,7 +657,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
         launched = _launch_pass2_batches(net, job.emb, job.plan, pts_d, pairs_d, valid_d, K, 0)
         if prof and lane.cuda:
             job.t[3].record()
-        job.scores, job.e2 = lane.download(job.pool, "score", [sc for _, _, sc in launched])
+        job.scores, job.e2 = lane.download(job.pool, "score", [sc for _, sc in launched])
         if prof and lane.cuda:
             job.t[4].record()
         job.emb = None
@@ -620,7 +679,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
                 t = job.t
                 print(f"[infer_imgs] device: pass 1 {t[0].elapsed_time(t[1]):.1f} ms, mask download -> pass 2 start {t[1].elapsed_time(t[2]):.1f} ms, "
                       f"pass 2 {t[2].elapsed_time(t[3]):.1f} ms, score download {t[3].elapsed_time(t[4]):.1f} ms", flush=True)
-            job.votes = _vote_sums(job.fq, 0, [(off, end, sc.numpy()) for (off, end, _, _), sc in zip(job.plan, job.scores)], n_pts, K)
+            job.votes = _vote_sums(job.fq, 0, [(tiles, sc.numpy()) for (tiles, _, _), sc in zip(job.plan, job.scores)], n_pts, K)
         edges = votes_to_edges(*job.votes, n_pts, config.TOPO_THRESHOLD)
         lap("votes -> edges")
         return nodes, edges, job.kp_mask, job.road_mask

@@ -449,14 +449,28 @@ def test_pass2_pack_matches_per_tile_collate():
     assert (np.diff(fq.offsets) == 0).any() and (np.diff(fq.offsets) > 20).any()
     K, bs = 16, 5
     junk = lambda name, shape, dtype: np.full(shape, 77, dtype)
-    plan, p_h, q_h, v_h = inf._pack_pass2_batches(fq, 0, len(infos), bs, K, junk)
-    assert len(plan) >= 2
-    for off, end, n_max, base in plan:
-        tiles = [fq.tile(t) for t in range(off, end)]
-        sl = slice(base, base + (end - off) * n_max)
-        np.testing.assert_array_equal(p_h[sl].reshape(end - off, n_max, 2), inf._collate([t[1].astype(np.float32) for t in tiles]))
-        np.testing.assert_array_equal(q_h[sl].reshape(end - off, n_max, K, 2), inf._collate([t[2].astype(np.int32) for t in tiles]))
-        np.testing.assert_array_equal(v_h[sl].reshape(end - off, n_max, K), inf._collate([t[3].astype(np.uint8) for t in tiles]))
+    counts = np.diff(fq.offsets)
+    for sort_tiles in (False, True):             # the reference's batches of consecutive tiles / tiles grouped by row count
+        plan, p_h, q_h, v_h = inf._pack_pass2_batches(fq, 0, len(infos), bs, K, junk, sort_tiles=sort_tiles)
+        assert len(plan) >= 2
+        seen = np.concatenate([t for t, _, _ in plan])
+        assert len(set(seen.tolist())) == len(seen) and set(np.flatnonzero(counts > 0).tolist()) <= set(seen.tolist())
+        rows = 0
+        for tile_idx, n_max, base in plan:
+            assert base == rows and n_max == counts[tile_idx].max() and len(tile_idx) <= bs
+            nb = len(tile_idx)
+            rows += nb * n_max
+            tiles = [fq.tile(int(t)) for t in tile_idx]
+            sl = slice(base, base + nb * n_max)
+            np.testing.assert_array_equal(p_h[sl].reshape(nb, n_max, 2), inf._collate([t[1].astype(np.float32) for t in tiles]))
+            np.testing.assert_array_equal(q_h[sl].reshape(nb, n_max, K, 2), inf._collate([t[2].astype(np.int32) for t in tiles]))
+            np.testing.assert_array_equal(v_h[sl].reshape(nb, n_max, K), inf._collate([t[3].astype(np.uint8) for t in tiles]))
+        if sort_tiles:
+            sorted_rows = rows
+            assert all(counts[t].min() > 0 for t, _, _ in plan)                      # empty tiles join no batch
+        else:
+            scan_rows = rows
+    assert sorted_rows <= scan_rows
 
 
 def test_pass2_vote_sums_equal_reference_dicts():
@@ -501,6 +515,23 @@ def test_pass2_vote_sums_equal_reference_dicts():
                 np.testing.assert_array_equal(a, b)
     finally:
         inf.worker_threads = wt
+    # where a tile's scores lie does not matter: the same scores in batches of tiles grouped by row count give the same sums
+    plan, _ = inf._pass2_plan(fq, bs, sort_tiles=True)
+    where = {}
+    for off, end, sc in batches:
+        for b in range(end - off):
+            where[off + b] = sc[b]
+    permuted = []
+    for tile_idx, n_max, _ in plan:
+        sc = np.full((len(tile_idx), n_max + 1, K), 7.0, np.float32)          # padding is never read
+        for jj, t in enumerate(tile_idx):
+            n = int(fq.offsets[t + 1] - fq.offsets[t])
+            sc[jj, :n] = where[int(t)][:n]
+        permuted.append((tile_idx, sc))
+    for a, b in zip(inf._vote_sums(fq, 0, permuted, n_pts, K), old):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(inf._votes_from_scores(fq, 0, permuted, n_pts, K), inf._votes_from_scores(fq, 0, batches, n_pts, K)):
+        np.testing.assert_array_equal(a, b)
     off, end, sc = batches[1]
     a = int(fq.offsets[off])
     j = int(np.argmax(fq.knn[a] >= 0))

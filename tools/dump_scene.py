@@ -29,12 +29,12 @@ kp, road = kp_u8.cpu().numpy(), road_u8.cpu().numpy()
 gp = extract_graph_points(kp, road, cfg)
 K = 16
 fq = I.build_all_patch_queries(gp, infos, 0, len(infos), cfg, flat=True)
-plan, pts_h, pairs_h, valid_h = I._pack_pass2_batches(fq, 0, len(infos), 64, K)
+plan, pts_h, pairs_h, valid_h = I._pack_pass2_batches(fq, 0, len(infos), 64, K, sort_tiles=False)      # batches of consecutive tiles
 pts_d, pairs_d, valid_d = (torch.from_numpy(x).to(dev) for x in (pts_h, pairs_h, valid_h))
 launched = I._launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, 0)
 out = {"kp": kp, "road": road, "graph_points": gp, "offsets": fq.offsets, "ids": fq.ids, "knn": fq.knn, "tied": fq.tied,
-       "plan": np.array(plan, dtype=np.int64)}
-for i, (off, end, sc) in enumerate(launched):
+       "plan": np.array([(int(t[0]), int(t[-1]) + 1, n_max, base) for t, n_max, base in plan], dtype=np.int64)}
+for i, (tiles, sc) in enumerate(launched):
     out[f"scores{i}"] = sc.cpu().numpy()
 nodes, edges, _, _ = I.infer_one_img(net, img, cfg)
 out["nodes"], out["edges"] = nodes, edges

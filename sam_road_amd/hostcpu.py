@@ -32,15 +32,25 @@ def usable_cpus():
     return max(1, n)
 
 
+def ranks_on_this_host():
+    """How many processes of the job share this host's CPUs (torchrun exports LOCAL_WORLD_SIZE): the host stages of every rank run
+    at the same time in the tile-sharded mode, so each rank sizes its worker pools for its share of the usable CPUs."""
+    try:
+        return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        return 1
+
+
 def worker_threads(cap=8):
-    """Thread count for the library's host-side worker pools (srh_pass2_fill): half of the usable CPUs, at most `cap`."""
-    return max(1, min(cap, usable_cpus() // 2))
+    """Thread count for the library's short host-side worker pools (mask scans, vote accumulation): half of this rank's share of
+    the usable CPUs, at most `cap`."""
+    return max(1, min(cap, usable_cpus() // ranks_on_this_host() // 2))
 
 
 def fill_threads(cap=16):
     """Thread count for srh_pass2_fill, the one host stage with tens of milliseconds of CPU work per scene (kNN of ~50k query rows):
-    every usable CPU, at most `cap` (measured on a 16-CPU quota: 23.4 ms on one thread, 4.3 on 8, 2.8 on 16)."""
+    every usable CPU of this rank's share, at most `cap` (measured on a 16-CPU quota: 23.4 ms on one thread, 4.3 on 8, 2.8 on 16)."""
     env = os.environ.get("SRH_FILL_THREADS")          # tuning aid
     if env:
         return max(1, int(env))
-    return max(1, min(cap, usable_cpus()))
+    return max(1, min(cap, usable_cpus() // ranks_on_this_host()))

@@ -380,6 +380,18 @@ def test_hostcpu_and_host_quiet_restore_process_state():
     from sam_road_amd.hostcpu import usable_cpus, worker_threads
     n = usable_cpus()
     assert 1 <= n <= len(os.sched_getaffinity(0)) and 1 <= worker_threads() <= max(1, n // 2) and worker_threads(cap=2) <= 2
+    from sam_road_amd.hostcpu import fill_threads
+    old = os.environ.get("LOCAL_WORLD_SIZE")
+    try:                                                   # the ranks of one node share its CPUs (torchrun's LOCAL_WORLD_SIZE)
+        os.environ["LOCAL_WORLD_SIZE"] = "1"
+        one = (worker_threads(), fill_threads())
+        os.environ["LOCAL_WORLD_SIZE"] = "4"
+        assert 1 <= fill_threads() <= max(1, n // 4) and 1 <= worker_threads() <= max(1, n // 8) and fill_threads() <= one[1]
+    finally:
+        if old is None:
+            os.environ.pop("LOCAL_WORLD_SIZE", None)
+        else:
+            os.environ["LOCAL_WORLD_SIZE"] = old
     was = inf._numpy_hugepages(True)                       # known starting point
     assert was in (True, False)
     try:
@@ -631,3 +643,31 @@ def test_votes_to_edges_matches_numpy_form():
         np.testing.assert_array_equal(got, numpy_form(uk, sums, cnts, first, n_pts, 0.499))
         assert got.dtype == np.int64 and got.shape[1] == 2 and 0 < len(got) < n
     assert votes_to_edges(uk[:0], sums[:0], cnts[:0], dense[:0], n_pts, 0.499).shape == (0, 2)
+
+
+def test_pass2_vote_sums_on_a_tile_sub_range():
+    """srh_pass2_vote_sums called through the C ABI for tiles [t0, t0 + nb) only (offsets pointer advanced, ids / knn absolute): the
+    sums of exactly those tiles' votes, first-vote positions counted from the sub-range's first vote."""
+    import ctypes as C
+    from sam_road_amd import inferencer as inf
+    lib = _lib.load()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(17)
+    pts = np.unique(rng.integers(0, 300, size=(500, 2)), axis=0).astype(np.int64)
+    cfg = Config(NEIGHBOR_RADIUS=40, MAX_NEIGHBOR_QUERIES=16)
+    infos = get_patch_info_one_img(0, 320, 0, 128, 4)
+    fq = inf.build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+    K, n_pts, t0, nb = 16, pts.shape[0], 5, 6
+    n_max = int(np.diff(fq.offsets[t0:t0 + nb + 1]).max())
+    sc = rng.random((nb, n_max, K)).astype(np.float32)
+    want = inf._accumulate_votes(*inf._votes_from_scores(fq, 0, [(t0, t0 + nb, sc)], n_pts, K))
+    cap = int(fq.knn.size)
+    uk, su, cn, fi = np.empty(cap, np.int64), np.empty(cap, np.float64), np.empty(cap, np.float64), np.empty(cap, np.int64)
+    nu = C.c_int64(0)
+    ptrs = (C.c_void_p * 1)(sc.ctypes.data)
+    tile0, cnt, nm = np.zeros(1, np.int32), np.full(1, nb, np.int32), np.full(1, n_max, np.int64)
+    assert lib.srh_pass2_vote_sums(ptrs, vp(tile0), vp(cnt), vp(nm), 1, K, vp(fq.offsets[t0:]), nb, vp(fq.ids), vp(fq.knn), n_pts,
+                                   vp(uk), vp(su), vp(cn), vp(fi), cap, C.byref(nu), 3) == 0
+    assert nu.value == len(want[0]) > 50
+    for got, w in zip((uk, su, cn, fi), want):
+        np.testing.assert_array_equal(got[:nu.value], w)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 4
+#define SRH_ABI_VERSION 5
 
 typedef enum {
     SRH_OK = 0,
@@ -137,6 +137,12 @@ int srh_op_layernorm(srh_ctx* ctx, const float* x, const float* gamma, const flo
  * qkv bias fp16 [3*heads*64] (pad-key rows), win = 14 (windowed) or S (global). out fp16 [B*S*S, heads*64]. */
 int srh_op_attention(srh_ctx* ctx, const void* qkv_f16, const void* relpos_h_f16, const void* relpos_w_f16,
                      const void* bias_qkv_f16, int B, int S, int heads, int win, void* out_f16, void* stream);
+/* The same with the head dim as an argument: 64 (ViT-B / ViT-L) or 80 (ViT-H, toponet_vith_256.yaml;
+ * windows of 14 on any S, or the 16x16 global window).  Tables [2*win-1, head_dim], scale head_dim^-0.5
+ * (segment_anything Attention.__init__, model.py:245-258 instantiates it with the checkpoint's dims). */
+int srh_op_attention_hd(srh_ctx* ctx, const void* qkv_f16, const void* relpos_h_f16, const void* relpos_w_f16,
+                        const void* bias_qkv_f16, int B, int S, int heads, int head_dim, int win,
+                        void* out_f16, void* stream);
 
 /* profiling --------------------------------------------------------------------------------------- */
 

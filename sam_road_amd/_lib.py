@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRH_LIB_PATH") or os.path.join(_HERE, "libsamroad_hip.so")
 
 SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SrhError(RuntimeError):
@@ -54,6 +54,7 @@ SYMBOLS = {
     "srh_op_conv3x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "srh_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "srh_op_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "srh_op_attention_hd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "srh_nms_points_host": (_I, [_P, _P, C.c_int64, C.c_int32, _P]),
     "srh_pass2_count": (_I, [_P, C.c_int64, _P, C.c_int32, _P]),
     "srh_pass2_fill": (_I, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, C.c_int32]),

@@ -958,19 +958,31 @@ extern "C" int srh_op_layernorm(srh_ctx* c, const float* x, const float* gamma, 
     return 0;
 }
 
-extern "C" int srh_op_attention(srh_ctx* c, const void* qkv, const void* rel_h, const void* rel_w, const void* bias_qkv,
-                                int B, int S, int heads, int win, void* out, void* stream) {
-    if (!c || !qkv || !rel_h || !rel_w || !bias_qkv || !out) return fail(c, SRH_ERR_BAD_ARG, "srh_op_attention: null argument");
+static int op_attention_impl(srh_ctx* c, const char* who, const void* qkv, const void* rel_h, const void* rel_w, const void* bias_qkv,
+                             int B, int S, int heads, int hd, int win, void* out, void* stream) {
+    if (!c || !qkv || !rel_h || !rel_w || !bias_qkv || !out) return fail(c, SRH_ERR_BAD_ARG, std::string(who) + ": null argument");
+    if (hd != 64 && hd != 80) return fail(c, SRH_ERR_BAD_ARG, std::string(who) + ": head dim must be 64 or 80");
     hipSetDevice(c->device);
     hipStream_t s = (hipStream_t)stream;
-    const int hd = 64, D = heads * hd;
-    const size_t T = (size_t)B * S * S;
+    const int D = heads * hd;
     AttnParams ap;
     ap.table_h = (const f16*)rel_h; ap.table_w = (const f16*)rel_w;     // fused rel-pos bias (default)
     ap.qkv = (const f16*)qkv; ap.ld = 3 * D; ap.bias_qkv = (const f16*)bias_qkv;
-    ap.out = (f16*)out; ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = win; ap.scale = 0.125f;
+    ap.out = (f16*)out; ap.ldo = D; ap.B = B; ap.S = S; ap.heads = heads; ap.hd = hd; ap.win = win;
+    ap.scale = 1.0f / sqrtf((float)hd);
     TRYK(c, "attention", attn_flops(B, S, heads, hd, win), 0, s, launch_attention(ap, s));
     return 0;
+}
+
+extern "C" int srh_op_attention(srh_ctx* c, const void* qkv, const void* rel_h, const void* rel_w, const void* bias_qkv,
+                                int B, int S, int heads, int win, void* out, void* stream) {
+    return op_attention_impl(c, "srh_op_attention", qkv, rel_h, rel_w, bias_qkv, B, S, heads, 64, win, out, stream);
+}
+
+// head dim as an argument: 64 (ViT-B/L, attention.hip) or 80 (ViT-H, attention_hdx.hip)
+extern "C" int srh_op_attention_hd(srh_ctx* c, const void* qkv, const void* rel_h, const void* rel_w, const void* bias_qkv,
+                                   int B, int S, int heads, int hd, int win, void* out, void* stream) {
+    return op_attention_impl(c, "srh_op_attention_hd", qkv, rel_h, rel_w, bias_qkv, B, S, heads, hd, win, out, stream);
 }
 
 // ---- profiling ------------------------------------------------------------------------------------------------

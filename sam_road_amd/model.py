@@ -250,7 +250,15 @@ class SAMRoad(nn.Module):
         return out
 
     def _apply(self, fn, *args, **kwargs):
+        # a model that runs on an IMPORTED arena (share_packed_weights) keeps it across an _apply that moved nothing
+        # (net.to(same_device), .cuda(), .float()): its Python parameters are not what it computes with, so dropping the
+        # arena here would make the next call re-pack this rank's never-loaded parameters
+        before = self._stamp() if self._imported else None
         out = super()._apply(fn, *args, **kwargs)
+        if self._imported:
+            self._stamp_tensors = None
+            if self._stamp() == before:
+                return out
         self._invalidate()
         return out
 
@@ -340,6 +348,9 @@ class SAMRoad(nn.Module):
         hit = self._packed.get(idx)
         if hit is not None:
             return hit
+        if self._imported:      # whatever dropped the arena (or another device index asked for it): never re-pack local parameters
+            raise _lib.SrhError("this model computes with packed weights imported from another rank (share_packed_weights) and has "
+                                "none for cuda:%d — re-share the weights instead of re-packing this rank's parameters" % idx)
         ctx = _lib.Context.get(idx)
         sd = {k: v.detach().to(torch.float32).cpu().contiguous() for k, v in self.state_dict().items()}
         # fold LoRA adapters into the fused qkv weight (q rows [0:D], v rows [2D:3D]; model.py:179-185)

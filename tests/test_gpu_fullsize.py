@@ -257,3 +257,14 @@ def test_heavy_tailed_weights(scale):
     ms_r, e_r = oracle.infer_masks_and_img_features(rgb)
     ms, e = net.infer_masks_and_img_features(rgb.cuda())
     check_masks_emb(f"heavy_tailed_x{int(scale)}", e, e_r, ms, ms_r)
+
+
+def test_heavy_tailed_weights_vith():
+    """The same outlier-channel stress on toponet_vith_256.yaml (BASELINE configs[4]): head dim 80 runs attention_hdx.hip
+    (XOR-swizzled 160-byte K rows, V^T without its zero rows), whose logits under 0.02-std weights stay at sigma ~ 0.5 —
+    with the scaled qkv channels they do not.  All 32 blocks, B = 2."""
+    oracle, net = build_pair(VITH_256, seed=4322, mutate=_heavy_tails(10.0))
+    rgb = synth_tiles(2, 256, seed=6)
+    ms_r, e_r = oracle.infer_masks_and_img_features(rgb)
+    ms, e = net.infer_masks_and_img_features(rgb.cuda())
+    check_masks_emb("heavy_tailed_x10_vith256", e, e_r, ms, ms_r)

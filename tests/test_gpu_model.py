@@ -236,6 +236,12 @@ def test_packed_weights_export_import_roundtrip():
     got = other(rgb, points, pairs, valid)
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+    # an _apply that moves nothing must not make the model fall back to its own (never loaded) parameters
+    other.to("cuda")
+    other.cuda()
+    other.float()
+    for a, b in zip(want, other(rgb, points, pairs, valid)):
+        assert torch.equal(a, b)
     wrong = SAMRoad(Config(cfg | dict(ENCODER_DEPTH=1, ENCODER_GLOBAL_ATTN_INDEXES=[])))
     wrong.eval().to("cuda")
     with pytest.raises(_lib.SrhError):
@@ -244,6 +250,13 @@ def test_packed_weights_export_import_roundtrip():
         next(other.parameters()).add_(1.0)
     with pytest.raises(_lib.SrhError):
         other.infer_masks_and_img_features(rgb)
+    # ... and once the arena is gone for any reason the imported model refuses instead of re-packing
+    third = SAMRoad(Config(cfg))
+    third.eval().to("cuda")
+    third.import_packed(buf.clone())
+    third._invalidate()
+    with pytest.raises(_lib.SrhError):
+        third.infer_masks_and_img_features(rgb)
 
 
 def test_packed_weights_through_rccl_broadcast():

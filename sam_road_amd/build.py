@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsamroad_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_q192.hip", "norm.hip", "patch.hip", "attention.hip", "attention_hdx.hip", "decoder.hip", "sam_decoder.hip", "topo.hip", "topo_fused.hip", "host_geom.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_q192.hip", "gemm_z192.hip", "norm.hip", "patch.hip", "attention.hip", "attention_hdx.hip", "decoder.hip", "sam_decoder.hip", "topo.hip", "topo_fused.hip", "host_geom.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -27,7 +27,7 @@ def source_id():
     """sha256 over every file the library is built from (csrc/*, the public header, the flags), 16 hex digits.  It is compiled
     into the library (srh_build_id()), so "is this .so the build of THESE sources" is a content check, not an mtime guess."""
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h", ".inc")))
     files.append(os.path.join(HERE, "..", "include", "samroad_hip.h"))
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")

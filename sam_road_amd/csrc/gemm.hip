@@ -625,6 +625,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
     const int variant = p.variant ? p.variant : env_variant;
     if (variant >= 50 && variant <= 62) return launch_gemm_q192(p, stream, variant - 50);
+    if (variant == 70) return launch_gemm_z192(p, stream);
 #else
     const int variant = 0;
 #endif

@@ -7,12 +7,12 @@ cd "$(dirname "$0")/../.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING"
 mkdir -p tools/probes/build
-for f in gemm gemm_q192; do
+for f in gemm gemm_q192 gemm_z192; do
   $HIPCC $FLAGS -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
 done
 $HIPCC $FLAGS -c tools/probes/gemm_probe.hip -o tools/probes/build/gemm_probe.o &
 wait
-$HIPCC --offload-arch=gfx950 tools/probes/build/gemm_probe.o tools/probes/build/gemm.o tools/probes/build/gemm_q192.o -o tools/probes/gemm_probe
-for p in feed_probe pipe_probe mfma_probe dma_probe; do
+$HIPCC --offload-arch=gfx950 tools/probes/build/gemm_probe.o tools/probes/build/gemm.o tools/probes/build/gemm_q192.o tools/probes/build/gemm_z192.o -o tools/probes/gemm_probe
+for p in feed_probe pipe_probe mfma_probe dma_probe feedx_probe mfma_data_probe; do
   [ -f tools/probes/$p.hip ] && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p
 done

@@ -42,7 +42,7 @@ __device__ __forceinline__ void tile_of(int vb, int ntiles, int tiles_m, int til
     xs = (within / gsz) % min(tiles_n, 32 / GR);
 }
 
-template <int TJ, int RD, int MM, int DMA, int D, int WARM>
+template <int TJ, int RD, int MM, int DMA, int D, int WARM, int SYNC = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void feedx_kernel(FP p) {
     constexpr int TN = 64 * TJ, WB = TN * 128, XB = 32768, BUF = WB + XB;
@@ -80,6 +80,8 @@ void feedx_kernel(FP p) {
         if (l_ < wrows) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_vptr)(smem + 2 * BUF + wave * 256), 4, (w_ws * wrows + l_) * p.ldw * 2, w_n0 * p.ldw * 2 + w_kt * 128, 0, 0); } \
     ++w_step; if (++w_kt == nk) { w_kt = 0; ++w_ti; if (w_step < S_total) tile_of<TN>(blockIdx.x + w_ti * G, ntiles, tiles_m, tiles_n, p.GR, w_m0, w_n0, w_xs, w_ws); } } }
 
+    int* const sync_cnt = reinterpret_cast<int*>(smem + 2 * BUF + 1024);
+    if (threadIdx.x == 0) *sync_cnt = 0;
     const int frow = lane & 31, fkey = (frow >> 1) & 7, fhalf = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     int choff[4];
@@ -130,8 +132,16 @@ void feedx_kernel(FP p) {
             if (DMA == 2) MMD(0, Q0 + Q1, Q2, tb) else MMD(0, 0, 0, tb)
             // hand-over: k-tile s+b+1 has landed (this wave's pieces) -> barrier -> its first fragments
             if (DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWAIT) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (SYNC == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else if (SYNC == 2) {
+                // soft barrier: a monotonic arrival counter in LDS instead of s_barrier (which drains the matrix pipe of a
+                // one-wave-per-SIMD kernel: nothing else is there to issue while the wave sits in it)
+                if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int want = 4 * (s + b + 1);
+                while (__builtin_amdgcn_readfirstlane(*(volatile int*)sync_cnt) < want) {}
+            }
             RDF(0, b ^ 1, 0)
             if (DMA == 2) MMD(1, Q0 + Q1 + Q2, Q3, tb) else MMD(1, 0, 0, tb)
         }
@@ -145,24 +155,26 @@ void feedx_kernel(FP p) {
 
 static float* g_out; static unsigned long long* g_cyc;
 
-template <int TJ, int RD, int MM, int DMA, int D, int WARM>
+template <int TJ, int RD, int MM, int DMA, int D, int WARM, int SYNC = 0>
 void run(const char* name, FP p) {
     constexpr int TN = 64 * TJ, BUF = TN * 128 + 32768, LDS = 2 * BUF + 2048;
     p.out = g_out; p.cyc = g_cyc;
-    auto kern = feedx_kernel<TJ, RD, MM, DMA, D, WARM>;
+    auto kern = feedx_kernel<TJ, RD, MM, DMA, D, WARM, SYNC>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    const int nb = 256;
+    const int nb = std::min(256, (p.M / 256) * (p.N / TN));      // persistent: one workgroup per CU, never more than tiles
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ts;
-    for (int rep = 0; rep < 6; ++rep) {
+    constexpr int NL = 20;       // back-to-back launches per timing: the clock / power state of a continuous stream, not of one 60 us burst from idle
+    for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), LDS, 0, p);
+        for (int l = 0; l < NL; ++l) hipLaunchKernelGGL(kern, dim3(nb), dim3(256), LDS, 0, p);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) ts.push_back(ms);
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) ts.push_back(ms / NL);
     }
     std::sort(ts.begin(), ts.end());
     const double us = ts[ts.size() / 2] * 1e3, usmin = ts[0] * 1e3;
     const int ntiles = (p.M / 256) * (p.N / TN);
+    fflush(stdout);
     const double steps = (double)((ntiles + nb - 1) / nb) * (p.K / 64);
     std::vector<unsigned long long> hc(nb); CK(hipMemcpy(hc.data(), g_cyc, nb * 8, hipMemcpyDeviceToHost));
     double avg = 0; for (auto v : hc) avg += (double)v; avg /= nb;
@@ -190,6 +202,13 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
         FP p{dA, dW, s.M, s.N, s.K, s.K, s.K, 4, 2, nullptr, nullptr};
         printf("=== %s  M=%d N=%d K=%d   (256 x 192 tiles: wave tile 128 x 96, 56 KiB per k-tile)\n", s.name, s.M, s.N, s.K);
+        run<3, 0, 1, 0, 1, 0>("MFMA only", p);
+        run<3, 0, 1, 0, 1, 0, 1>("MFMA only, NO barrier", p);
+        run<3, 0, 1, 0, 1, 0, 2>("MFMA only, LDS-counter barrier", p);
+        run<3, 1, 1, 0, 1, 0, 1>("reads + MFMA, NO barrier", p);
+        run<3, 1, 1, 0, 1, 0, 2>("reads + MFMA, LDS-counter barrier", p);
+        run<3, 1, 1, 2, 2, 0, 1>("reads + MFMA + DMA woven, lookahead 2, NO barrier", p);
+        run<3, 1, 1, 2, 2, 0, 2>("reads + MFMA + DMA woven, lookahead 2, LDS-counter barrier", p);
         run<3, 1, 1, 0, 1, 0>("reads + MFMA (no feed)", p);
         run<3, 0, 0, 1, 1, 0>("DMA only, burst, lookahead 1", p);
         run<3, 0, 0, 1, 2, 0>("DMA only, burst, lookahead 2", p);

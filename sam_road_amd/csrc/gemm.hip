@@ -625,13 +625,21 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
     const int variant = p.variant ? p.variant : env_variant;
     if (variant >= 50 && variant <= 62) return launch_gemm_q192(p, stream, variant - 50);
-    if (variant == 70) return launch_gemm_z192(p, stream);
+    if (variant >= 70 && variant <= 76) return launch_gemm_z192(p, stream, variant - 70);
 #else
     const int variant = 0;
 #endif
     // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
     static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
-    if (variant == 0 && use_q192 && q192_preferred(p)) return launch_gemm_q192(p, stream, 0);
+    if (variant == 0 && use_q192 && q192_preferred(p)) {
+        // hand-scheduled successor (gemm_z192.hip) wherever it applies (bias, no activation / GELU); q192 keeps the rest
+#ifdef SRH_TUNING
+        static const bool use_z192 = !(getenv("SRH_GEMM_Z192") && atoi(getenv("SRH_GEMM_Z192")) == 0);    // probe builds: A/B against q192
+        if (!use_z192) return launch_gemm_q192(p, stream, 0);
+#endif
+        if (z192_supported(p)) return launch_gemm_z192(p, stream);
+        return launch_gemm_q192(p, stream, 0);
+    }
     if (variant == 1) return launch_cfg<0, 2, 2, 2, 2>(p, stream);
     if (variant == 2 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<0, 4, 2, 2, 4>(p, stream);
     static bool attr_set = false;

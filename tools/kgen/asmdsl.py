@@ -97,7 +97,7 @@ class Mod:
         self.r, self.neg, self.ab = r, neg, ab
 
     def __str__(self):
-        s = f"|{self.r}|" if self.ab else str(self.r)
+        s = f"abs({self.r})" if self.ab else str(self.r)       # not |v|: '|' is a dialect separator inside an inline-asm string
         return "-" + s if self.neg else s
 
 
@@ -389,6 +389,25 @@ class Prog:
     def v_and_or_b32(self, d, a, b, c):
         self._v_op("v_and_or_b32", lambda x, y, z: (x & y) | z, d, [a, b, c])
 
+    def v_cmp_eq_u32(self, a, b):
+        """vcc = (a == b) per lane"""
+        a, b = self._lit(a), self._lit(b)
+
+        def emu(st):
+            m = self._vsrc(st, a) == self._vsrc(st, b)
+            st.special["vcc"] = int(sum(1 << i for i in range(64) if m[i]))
+        self.add(f"v_cmp_eq_u32 vcc, {a}, {b}", emu, "valu", [a, b], [VCC])
+
+    def v_cndmask_b32(self, d, a, b):
+        """d = vcc ? b : a"""
+        a, b = self._lit(a), self._lit(b)
+
+        def emu(st):
+            vcc = st.special["vcc"]
+            m = np.array([(vcc >> i) & 1 for i in range(64)], dtype=bool)
+            self._vwrite(st, d, np.where(m, self._vsrc(st, b), self._vsrc(st, a)))
+        self.add(f"v_cndmask_b32 {d}, {a}, {b}, vcc", emu, "valu", [a, b, VCC], [d])
+
     def v_mbcnt_lane_id(self, d, tmp_ok=True):
         """d = lane id (v_mbcnt_lo + v_mbcnt_hi with an all-ones mask)."""
         self.add(f"v_mbcnt_lo_u32_b32 {d}, -1, 0", lambda st: self._vwrite(st, d, np.minimum(np.arange(64), 32).astype(np.uint32)), "valu", [], [d])
@@ -517,11 +536,17 @@ class Prog:
             if st.wg.ds_lazy:
                 for i in range(4):
                     tgt[d.idx + i] = np.full(64, POISON, np.uint32)
+                box = {"w": None}
+
+                def sample_now():                 # called early by a later ds_write of the same wave (in-order LDS queue)
+                    if box["w"] is None:
+                        box["w"] = sample()
 
                 def deliver():
-                    w = sample()
+                    sample_now()
                     for i in range(4):
-                        tgt[d.idx + i] = w[:, i].copy()
+                        tgt[d.idx + i] = box["w"][:, i].copy()
+                deliver.sample_now = sample_now
                 st.issue_lgkm(deliver)
             else:
                 w = sample()
@@ -529,6 +554,36 @@ class Prog:
                     tgt[d.idx + i] = w[:, i].copy()
                 st.issue_lgkm(lambda: None)
         self.add(f"ds_read_b128 {d}, {addr}" + (f" offset:{offset}" if offset else ""), emu, "ds", [addr], [d])
+
+    def ds_write_b64(self, addr, data, offset=0):
+        """A wave's LDS instructions execute in issue order: its own earlier reads sample LDS before this write lands."""
+        assert data.n == 2 and 0 <= offset <= 65535 and offset % 8 == 0
+
+        def emu(st):
+            st.flush_ds_reads()
+            ad = st.v[addr.idx].astype(np.int64) + offset
+            assert (ad % 8 == 0).all() and (ad >= 0).all() and (ad + 8 <= st.wg.lds.size).all(), "ds_write_b64 address"
+            src = st.v if data.file == "v" else st.a
+            w = np.stack([src[data.idx], src[data.idx + 1]], axis=1).copy().view(np.uint8).reshape(64, 8)
+            m = st.exec_mask()
+            for l in np.nonzero(m)[0]:          # lane order: a higher lane wins an address clash, as in hardware
+                st.wg.lds[ad[l]:ad[l] + 8] = w[l]
+            st.issue_lgkm(lambda: None)
+        self.add(f"ds_write_b64 {addr}, {data}" + (f" offset:{offset}" if offset else ""), emu, "ds", [addr, data], [])
+
+    def ds_write_b128(self, addr, data, offset=0):
+        assert data.n == 4 and 0 <= offset <= 65535 and offset % 16 == 0
+
+        def emu(st):
+            st.flush_ds_reads()
+            ad = st.v[addr.idx].astype(np.int64) + offset
+            assert (ad % 16 == 0).all() and (ad >= 0).all() and (ad + 16 <= st.wg.lds.size).all(), "ds_write_b128 address"
+            src = st.v if data.file == "v" else st.a
+            w = np.stack([src[data.idx + k] for k in range(4)], axis=1).copy().view(np.uint8).reshape(64, 16)
+            for l in np.nonzero(st.exec_mask())[0]:
+                st.wg.lds[ad[l]:ad[l] + 16] = w[l]
+            st.issue_lgkm(lambda: None)
+        self.add(f"ds_write_b128 {addr}, {data}" + (f" offset:{offset}" if offset else ""), emu, "ds", [addr, data], [])
 
     # ---------------------------------------------------------------------------------------- VMEM
     def buffer_load_lds(self, nbytes, voff, rsrc, soff):
@@ -609,6 +664,11 @@ class WaveState:
     def issue_lgkm(self, fn, smem=False):
         self.lgkm.append((fn, smem))
         assert len(self.lgkm) <= 15 or True
+
+    def flush_ds_reads(self):
+        for fn, _ in self.lgkm:
+            if hasattr(fn, "sample_now"):
+                fn.sample_now()
 
     def wait_vm(self, n):
         while len(self.vm) > n:

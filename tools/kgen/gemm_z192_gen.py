@@ -24,7 +24,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmdsl import A, EXEC_HI, EXEC_LO, M0, Prog, S, V, Workgroup, check_hazards, neg  # noqa: E402
+from asmdsl import A, EXEC_HI, EXEC_LO, M0, Prog, S, V, Workgroup, check_hazards, nabs, neg, vabs  # noqa: E402
 
 # ---------------------------------------------------------------------------------------------- fixed register map
 KARG, BID, WAVE = S(36, 2), S(38), S(39)
@@ -32,7 +32,7 @@ RS_X, RS_W, RS_O, RS_B = S(40, 4), S(44, 4), S(48, 4), S(52, 4)
 CUR, NXT = S(56, 4), S(60, 4)            # tile table entries {x_off, w_off, out_off, bias_off} (bytes)
 LDA, LDW, LDC, NTILES = S(64), S(65), S(66), S(67)
 NKB, GRID, A_BYTES, W_BYTES = S(68), S(69), S(70), S(71)
-O_BYTES, B_BYTES, FLAGS, PAD0 = S(72), S(73), S(74), S(75)
+O_BYTES, B_BYTES, LDC16, PAD0 = S(72), S(73), S(74), S(75)      # LDC16 (row-block store step) overwrites the unused flags dword
 TABLE = S(76, 2)
 DW, DWL, DX, DXL = S(78), S(79), S(80), S(81)       # DMA streams: soffset of the stream's k-tile, k-tiles left in its tile
 NK, WLDS = S(82), S(83)
@@ -45,11 +45,17 @@ KBL = S(94)                               # bodies left in the current tile
 T0, T1, T2, T3 = S(95), S(96), S(97), S(98)
 HAVEP, G16 = S(99), S(75)          # G16 reuses the padding dword of the last kernarg quad
 
-TID, LANE, VW, VX = V(4), V(5), V(6), V(7)
+TID, LANE, VW, VX = V(4), V(5), V(54), V(55)   # v4..v7 become a bias quad once the prologue is done with TID / LANE
 WF = V(8, 4)                              # W fragment LDS address per k-step
 XF = V(12, 12)                            # X fragment LDS address per (slot, k-step)
-VO, VB, VBD, VC0, VBL = V(24), V(25), V(26), V(27), V(28)
-TMP = V(30, 34)                           # v30..v63 (even base: register tuples must be 64-bit aligned on gfx90a+)
+VB, VBD, VC0, VBL = V(25), V(26), V(27), V(28)
+BQ = [V(30, 4), V(34, 4), V(50, 4), V(4, 4)]   # the 16 bias values of a W block (4 column groups); tuples are 64-bit aligned on gfx90a+
+GT = V(38, 12)                            # GELU temporaries: 4 elements in flight x (r, e, m)
+GC = [S(70), S(71), S(72), S(73)]         # GELU coefficients c1..c4 in the SGPRs the buffer sizes came in (c0 in VC0, c5 = 1.0 inline)
+TMP = GT                                  # prologue scratch (the GELU temporaries are idle then)
+VS = V(29)                                # staging write address: row (lane & 31), 16-byte half (lane >> 5)
+VR = [V(57), V(58), V(59)]                # staging read-back address per 1 KiB
+VGO = [V(60), V(61), V(24)]               # global store offset of the read-back lane
 SETB = V(64, 192)
 ACC = A(0, 192)
 
@@ -63,7 +69,9 @@ def FRX(set_, j):
 
 
 W_SLOT, X_BASE, X_SLOT, BIAS_LDS = 24576, 49152, 32768, 147456
-LDS_BYTES = BIAS_LDS + 2 * 768
+STG_LDS, STG_WAVE, STG_ROW = BIAS_LDS + 2 * 768, 3648, 112     # per-wave output staging: 32 rows x 112 B (96 B of data)
+LDS_BYTES = STG_LDS + 4 * STG_WAVE
+assert LDS_BYTES <= 160 * 1024
 
 # kernarg layout (struct ZParams in gemm_z192.hip)
 K_A, K_W, K_BIAS, K_OUT, K_TABLE = 0, 8, 16, 24, 32
@@ -139,13 +147,39 @@ class ZGen:
             for slot in range(3):
                 p.v_add_u32(XF[slot * 4 + ks], T3, c)
                 p.v_add_u32(XF[slot * 4 + ks], X_BASE + slot * X_SLOT, XF[slot * 4 + ks])
-        # output lane offset: (wm*128 + frow) * ldc2 + wn*192 + fhalf*16
-        p.s_lshl_b32(T3, T1, 7)
-        p.v_add_u32(t3, T3, t0)
-        p.v_mul_lo_u32(t3, t3, LDC)
-        p.s_mul_i32(T2, T0, 192)
-        p.v_lshl_add_u32(t3, t1, 4, t3)
-        p.v_add_u32(VO, T2, t3)
+        # output staging (per wave, STG_LDS + wave*STG_WAVE): 32 rows x 112 B.  After the half-wave exchange a lane holds 16
+        # contiguous bytes of its row: lanes 0-31 the first, lanes 32-63 the second 8 columns of a 16-column group.
+        p.s_mul_i32(T2, WAVE, STG_WAVE)
+        p.s_add_u32(T2, T2, STG_LDS)                      # wave's staging base
+        p.s_mov_b32(KBL, STG_ROW)                         # VOP3 takes no literal on gfx9: constants through (idle) SGPRs
+        p.v_mul_lo_u32(t3, t0, KBL)                       # frow * 112
+        p.v_lshl_add_u32(t3, t1, 4, t3)                   # + fhalf*16
+        p.v_add_u32(VS, T2, t3)
+        # read-back: lane + 64 r = 6 * row + seg  (32 rows x 6 segments of 16 B = 3 KiB)
+        p.s_lshl_b32(T3, T1, 7)                           # wm * 128
+        p.s_mul_i32(T3, T3, LDC)
+        p.s_mul_i32(T0, T0, 192)                          # wn * 192   (T0 held wn)
+        p.s_add_u32(T3, T3, T0)
+        p.s_mov_b32(T1, 43691)
+        for r in range(3):
+            idx, row, seg = TMP[6], TMP[7], TMP[8]
+            p.v_add_u32(idx, 64 * r, LANE)
+            p.v_mul_lo_u32(row, idx, T1)
+            p.v_lshrrev_b32(row, 18, row)                  # idx // 6 (43691 / 2^18; exact for idx < 2^15)
+            p.v_mul_lo_u32(seg, row, 6)
+            p.v_sub_u32(seg, idx, seg)
+            p.v_lshlrev_b32(seg, 4, seg)
+            p.v_mul_lo_u32(idx, row, KBL)
+            p.v_add_u32(idx, idx, seg)
+            p.v_add_u32(VR[r], T2, idx)
+            p.v_mul_lo_u32(idx, row, LDC)
+            p.v_add_u32(idx, idx, seg)
+            p.v_add_u32(VGO[r], T3, idx)
+        p.s_lshl_b32(LDC16, LDC, 5)
+        p.s_sub_u32(LDC16, LDC16, 96)                     # store offset step between row blocks: 32 rows on, 96 B back
+        for k in range(4):
+            p.s_mov_b32(GC[k], float(GELU_C[k + 1]))
+        p.s_and_b32(T0, WAVE, 1)                          # wn again (T0 was reused)
         # bias: LDS read address (wn*96 + 4 fhalf) floats, DMA source offset wave*192 + lane*16
         p.s_mul_i32(T2, T0, 384)
         p.v_lshlrev_b32(t3, 4, t1)
@@ -273,114 +307,146 @@ class ZGen:
             return lambda: (p.ds_read_b128(FRX(set_, j), XF[xslot * 4 + ks], j * 4096), self.lg_log.append("F"))
         return [rx(0), rw(0), rx(1), rx(2), rx(3), rw(1), rw(2)]
 
-    # ------------------------------------------------------------------------------------------ epilogue pieces
-    def epi_items(self, t):
-        """The finished tile's accumulator tile t = 4 i + j (f32 in SETB[16t:16t+16]) -> bias, activation, fp16 pack,
-        half-wave exchange, two 16-byte stores.  Returned as a list of small emitters (each a few instructions) that the
-        caller weaves into MFMA gaps — or runs back to back for the exposed epilogue of a workgroup's last tile."""
+    # ------------------------------------------------------------------------------------------ epilogue atoms
+    def epi_atoms(self):
+        """The finished tile (f32 in SETB: accumulator tile t = 4 i + j at [16t, 16t+16), register 4q+e = row (lane&31) of
+        X block j, column 32 i + 8 q + 4 fhalf + e) -> bias, activation, fp16 pack, TRANSPOSE THROUGH LDS, 16-byte stores of
+        192-byte row segments.  Why the transpose: a store instruction costs the CU ~87 clk when its 64 lanes touch 32 rows
+        (the accumulator layout) and ~46 clk when they cover 5.3 rows of 192 B (profiles/r04_store_probe.txt), and with the
+        operand LDS-DMA the address path is the saturated resource of this kernel.
+        Returns atoms (issue slots, kind, emitter); kind 'vmem' atoms must not share an MFMA gap with an LDS-DMA piece."""
         p = self.p
-        i, j = t // 4, t % 4
-        B = SETB.sub(16 * t, 16)
-        bq = [TMP.sub(4 * q, 4) for q in range(4)]          # v28..v43: the 16 bias values of this accumulator tile
-        tmp = [[TMP[16 + 3 * e + k] for k in range(3)] for e in range(4)]     # GELU temporaries of 4 elements in flight
-        items = []
+        atoms = []
 
-        def bias_reads():
-            for q in range(4):
-                p.ds_read_b128(bq[q], VB, i * 128 + q * 32)
-                self.lg_log.append("E")
-        items.append(("lds4", bias_reads))
+        def atom(slots, kind, fn):
+            atoms.append((slots, kind, fn))
 
-        def wait_bias():
-            # every LDS op issued after the 4 bias reads may stay in flight
-            if "E" not in self.lg_log:
-                return
-            n = 0
-            for k in reversed(self.lg_log):
-                if k == "E":
-                    break
-                n += 1
-            assert n <= 15
-            p.s_waitcnt(lgkmcnt=n)
-            self.lg_log = self.lg_log[len(self.lg_log) - n:]
-        items.append(("wait", wait_bias))
-        for r0 in range(0, 16, 4):
-            def addb(r0=r0):
-                for r in range(r0, r0 + 4):
-                    p.v_add_f32(B[r], B[r], bq[r // 4][r % 4])
-            items.append(("valu4", addb))
-        if self.act == 1:
-            for r0 in range(0, 16, 4):
-                # 9 VALU per element, 4 elements interleaved for ILP
-                def g1(r0=r0):
-                    for e in range(4):
-                        p.v_and_b32(tmp[e][0], 0x7FFFFFFF, B[r0 + e])                 # a = |x|
-                    for e in range(4):
-                        p.v_fmaak_f32(tmp[e][1], VC0, tmp[e][0], GELU_C[1])
-                items.append(("valu8", g1))
-                for c in (2, 3):
-                    def g2(r0=r0, c=c):
-                        for e in range(4):
-                            p.v_fmaak_f32(tmp[e][1], tmp[e][1], tmp[e][0], GELU_C[c])
-                    items.append(("valu4", g2))
+        def atom_halves(fn4):
+            """A 4-element VALU step as two 2-slot atoms (elements 0-1, 2-3): finer packing into the gaps."""
+            atom(2, "valu", lambda: fn4(range(0, 2)))
+            atom(2, "valu", lambda: fn4(range(2, 4)))
 
-                def g3(r0=r0):
-                    for e in range(4):
-                        p.v_fmaak_f32(tmp[e][1], tmp[e][1], tmp[e][0], GELU_C[4])
-                    for e in range(4):
-                        p.v_fmaak_f32(tmp[e][1], tmp[e][1], tmp[e][0], GELU_C[5])
-                items.append(("valu8", g3))
+        def wait_lds(tag):
+            def fn():
+                if tag not in self.lg_log:
+                    return
+                n = 0
+                for k in reversed(self.lg_log):
+                    if k == tag:
+                        break
+                    n += 1
+                n = min(n, 15)          # the counter has 4 bits: lgkmcnt(15) already implies everything older than the youngest 15
+                p.s_waitcnt(lgkmcnt=n)
+                self.lg_log = self.lg_log[len(self.lg_log) - n:]
+            return fn
 
-                def g4(r0=r0):
-                    for e in range(4):
-                        p.v_exp_f32(tmp[e][2], neg(tmp[e][1]))                         # 2^-r
-                    for e in range(4):
-                        p.v_max_f32(tmp[e][1], 0, B[r0 + e])                           # max(x, 0)
-                items.append(("valu8", g4))
+        # bias / activation / pack, W block (i) outer: the 16 bias values of a W block serve its four accumulator tiles
+        for i in range(3):
+            for q0 in (0, 2):
+                def rd(i=i, q0=q0):
+                    for q in (q0, q0 + 1):
+                        p.ds_read_b128(BQ[q], VB, i * 128 + q * 32)
+                        self.lg_log.append("E")
+                atom(2, "lds", rd)
+            atom(1, "wait5", wait_lds("E"))       # not before 5 gaps after the reads: an LDS round trip is ~130 clk
+            for j in range(4):
+                B = SETB.sub(16 * (4 * i + j), 16)
+                for q in range(4):
+                    def addb(es, B=B, q=q):
+                        for e in es:
+                            p.v_add_f32(B[4 * q + e], B[4 * q + e], BQ[q][e])
+                    atom_halves(addb)
+                if self.act == 1:
+                    for g0 in range(0, 16, 4):
+                        x = [B[g0 + e] for e in range(4)]
+                        r_ = [GT[3 * e] for e in range(4)]
+                        e_ = [GT[3 * e + 1] for e in range(4)]
+                        m_ = [GT[3 * e + 2] for e in range(4)]
 
-                def g5(r0=r0):
-                    for e in range(4):
-                        p.v_fma_f32(B[r0 + e], neg(tmp[e][0]), tmp[e][2], tmp[e][1])    # max(x,0) - a 2^-r
-                items.append(("valu4", g5))
-        elif self.act == 2:
-            for r0 in range(0, 16, 4):
-                def relu(r0=r0):
-                    for r in range(r0, r0 + 4):
-                        p.v_max_f32(B[r], 0, B[r])
-                items.append(("valu4", relu))
+                        def f1(es, x=x, r_=r_):
+                            for e in es:
+                                p.v_fma_f32(r_[e], VC0, vabs(x[e]), GC[0])
+                        atom_halves(f1)
+                        for c in (1, 2, 3):
+                            def f2(es, x=x, r_=r_, c=c):
+                                for e in es:
+                                    p.v_fma_f32(r_[e], r_[e], vabs(x[e]), GC[c])
+                            atom_halves(f2)
 
-        def pack():
-            for q in range(4):
-                for d in range(2):
-                    p.v_cvt_pk_f16_f32(B[2 * q + d], B[4 * q + 2 * d], B[4 * q + 2 * d + 1])
-        items.append(("valu8", pack))
+                        def f5(es, x=x, r_=r_):
+                            for e in es:
+                                p.v_fma_f32(r_[e], r_[e], vabs(x[e]), 1.0)
+                        atom_halves(f5)
 
-        def swap():
-            p.s_nop(1)
-            for kp in range(2):
-                for d in range(2):
-                    p.v_permlane32_swap_b32(B[4 * kp + d], B[4 * kp + 2 + d])
-            # store soffset: out_off + j*32 rows + (i*32 + kp*16) columns
-            if j == 0:
-                p.s_add_u32(T2, PO, i * 64)
-            else:
-                p.s_add_u32(T2, T2, LDC32)
-            p.s_add_u32(T3, T2, 32)
-        items.append(("valu4", swap))
+                        def fe(es, r_=r_, e_=e_):
+                            for e in es:
+                                p.v_exp_f32(e_[e], neg(r_[e]))                       # 2^-r
+                        atom_halves(fe)
 
-        def store0():
-            p.buffer_store_dwordx4(B.sub(0, 4), VO, RS_O, T2)
-            self.vm_log.append("S")
-        items.append(("vmem", store0))
+                        def fm(es, x=x, m_=m_):
+                            for e in es:
+                                p.v_max_f32(m_[e], 0, x[e])                          # max(x, 0)
+                        atom_halves(fm)
 
-        def store1():
-            p.buffer_store_dwordx4(B.sub(4, 4), VO, RS_O, T3)
-            self.vm_log.append("S")
-        items.append(("vmem", store1))
-        return items
+                        def fo(es, x=x, e_=e_, m_=m_):
+                            for e in es:
+                                p.v_fma_f32(x[e], nabs(x[e]), e_[e], m_[e])          # max(x,0) - |x| 2^-r
+                        atom_halves(fo)
+                for q in range(4):
+                    def pack(B=B, q=q):
+                        for d in range(2):
+                            p.v_cvt_pk_f16_f32(B[2 * q + d], B[4 * q + 2 * d], B[4 * q + 2 * d + 1])
+                    atom(2, "valu", pack)
+        for j in range(4):
+            # the j-block's 32 rows x 96 columns (8 packed registers per accumulator tile) leave as two 48-column halves c:
+            # half-wave exchange (v_permlane32_swap) -> 16 contiguous bytes per lane -> ds_write_b128 into the wave's 32 x 96 B
+            # staging image -> ds_read_b128 as 96-byte row segments -> 16-byte stores.  Half 1's writes and read-back are issued
+            # BEFORE half 0's wait (a wave's LDS operations execute in issue order), so no wait sits right behind its reads.
+            if self.sched.get("no_stage"):
+                continue
+            nt = bool(self.sched.get("store_nt"))
+            groups = [[(0, 0), (0, 1), (1, 0)], [(1, 1), (2, 0), (2, 1)]]          # (W block i, column-group pair kp) per half
+            for c in range(2):
+                for g, (i, kp) in enumerate(groups[c]):
+                    B = SETB.sub(16 * (4 * i + j), 16)
+
+                    def sw(B=B, kp=kp):
+                        p.s_nop(1)                                # VALU write -> v_permlane32_swap: 2 wait states
+                        for d in range(2):
+                            p.v_permlane32_swap_b32(B[4 * kp + d], B[4 * kp + 2 + d])
+                    atom(2, "valu", sw)
+                for g, (i, kp) in enumerate(groups[c]):
+                    B = SETB.sub(16 * (4 * i + j), 16)
+
+                    def wr(B=B, kp=kp, g=g):
+                        p.ds_write_b128(VS, B.sub(4 * kp, 4), g * 32)
+                        self.lg_log.append("w")
+                    atom(2, "lds", wr)
+
+                def rb(c=c, j=j):
+                    for r, (i, kp) in enumerate(groups[c]):
+                        p.ds_read_b128(SETB.sub(16 * (4 * i + j) + 4 * kp, 4), VR[r])
+                        self.lg_log.append("R%d" % c)
+                atom(3, "lds", rb)
+            for c in range(2):
+                atom(1, "wait", wait_lds("R%d" % c))
+                for r, (i, kp) in enumerate(groups[c]):
+                    def st(r=r, i=i, kp=kp, c=c, j=j):
+                        if r == 0:
+                            if j == 0 and c == 0:
+                                p.s_mov_b32(T2, PO)
+                            elif c == 1:
+                                p.s_add_u32(T2, T2, 96)
+                            else:
+                                p.s_add_u32(T2, T2, LDC16)        # next row block: + 32 rows - 96 B
+                        if not self.sched.get("no_store"):
+                            p.buffer_store_dwordx4(SETB.sub(16 * (4 * i + j) + 4 * kp, 4), VGO[r], RS_O, T2, nt=nt)
+                            self.vm_log.append("S")
+                    atom(2, "vmem", st)
+        return atoms
 
     # ------------------------------------------------------------------------------------------ one k-tile
-    def ktile(self, kk, first, epi):
+    def ktile(self, kk, first, epi, drain=False):
         """k-tile kk (0..11) of a 12-k-tile body.  first: the tile's first k-tile (k-step 0 starts the accumulators with C = 0).
         epi: list of epilogue emitters (kind, fn) to weave into this k-tile's gaps (consumed front to back)."""
         p = self.p
@@ -410,24 +476,50 @@ class ZGen:
                 # operands of this k-step must have landed: frag reads were issued one k-step ago
                 if m == 0:
                     self.wait_frags()
+                    if ks == 3 and self.sched.get("barrier_before"):
+                        self.barrier_point()
+                if drain and ks == 0:
+                    # the PREVIOUS tile's accumulator tile m leaves for v[64:255] just before this tile's first MFMA (C = 0)
+                    # overwrites it: 16 v_accvgpr_read per gap instead of one exposed burst of 192 at the tile switch
+                    for r in range(16):
+                        p.v_accvgpr_read_b32(SETB[16 * m + r], ACC[16 * m + r])
                 p.v_mfma_f32_32x32x16_f16(acc, FRW(set_, i), FRX(set_, j), 0 if (first and ks == 0) else acc)
-                if ks == 3 and m == 0:
+                if ks == 3 and m == 0 and not self.sched.get("barrier_before"):
                     self.barrier_point()
                 if m < 7:
                     reads[m]()
                 if (ks, m) in dma_at:
                     dma_at[(ks, m)]()
-                # epilogue work: fill what is left of the gap
-                budget = self.sched.get("epi_per_gap", 1)
-                while epi and budget > 0:
-                    kind, fn = epi[0]
-                    if kind == "vmem" and ((ks, m) in dma_at):
+                nd = self.sched.get("dummy_valu", 0)     # probe: what does a filler cost in each kind of gap?
+                dk = self.sched.get("dummy_kind", "all")
+                if nd and (dk == "all" or (dk == "read" and m < 7) or (dk == "dma" and (ks, m) in dma_at) or
+                           (dk == "free" and m >= 7 and (ks, m) not in dma_at)):
+                    for k_ in range(nd):
+                        p.v_mov_b32(GT[k_ % 12], GT[(k_ + 5) % 12])
+                # deferred-epilogue atoms: paced over the body.  A 32-clk MFMA gap hides ~5 issue slots of the same wave
+                # (MI355X guide, one wave per SIMD): a gap that carries an LDS-DMA piece (3 slots, and the piece holds the
+                # wave ~60 clk by itself) takes nothing more; a fragment-read gap takes 4 more slots, a free gap 5.
+                is_dma = (ks, m) in dma_at
+                own = (1 if m < 7 else 0) + (3 if is_dma else 0)
+                room = self.sched.get("gap_slots", 7 if self.act == 1 else 5) - own
+                if is_dma and not self.sched.get("epi_in_dma_gaps"):
+                    room = 0
+                if drain and ks == 0:
+                    room = 0                        # the epilogue starts once its tile has been drained
+                self.credit += self.rate
+                self.gapno += 1
+                while epi and room >= epi[0][0] and self.credit >= epi[0][0] - 0.5:
+                    slots, kind, fn = epi[0]
+                    if kind == "vmem" and is_dma:
                         break                       # at most one VMEM instruction per gap
-                    if kind == "lds4" and m < 7:
+                    if kind == "wait5" and self.gapno - self.last_lds_gap < 5:
                         break
+                    if kind == "lds":
+                        self.last_lds_gap = self.gapno
                     epi.pop(0)
                     fn()
-                    budget -= 1
+                    room -= slots
+                    self.credit -= slots
 
     def wait_frags(self):
         """Before a k-step's first MFMA: the 7 fragment reads issued during the previous k-step have returned (LDS ops
@@ -439,7 +531,7 @@ class ZGen:
             if k == "F":
                 break
             n += 1
-        assert n <= 15
+        n = min(n, 15)
         self.p.s_waitcnt(lgkmcnt=n)
         self.lg_log = self.lg_log[len(self.lg_log) - n:]
 
@@ -460,31 +552,36 @@ class ZGen:
     # ------------------------------------------------------------------------------------------ body / tile / kernel
     def body(self, first, with_epi):
         epi = []
-        if with_epi:
-            for t in range(12):
-                epi += self.epi_items(t)
-        self.epi_total = len(epi)
+        if with_epi and not self.sched.get("no_epi"):
+            epi = self.epi_atoms()
+        # pacing: the atoms are spread over the first `span` k-tiles of the body at an even rate of issue slots per gap
+        span = self.sched.get("epi_span", 11)
+        self.rate = sum(a_[0] for a_ in epi) / (span * 34.0)        # ~34 of a k-tile's 48 gaps take epilogue work
+        self.credit = 0.0
+        self.gapno, self.last_lds_gap = 0, -100
         # canonical LDS-queue state at a body's entry (prologue and every body end leave exactly this): the 7 fragment reads of
         # the coming k-step are the youngest LDS operations
         self.lg_log = ["F"] * 7
+        drain = with_epi and first and not self.sched.get("no_epi") and not self.sched.get("burst_drain")
         for kk in range(12):
-            self.ktile(kk, first and kk == 0, epi)
+            self.ktile(kk, first and kk == 0, epi, drain and kk == 0)
         assert not epi, f"{len(epi)} epilogue items did not fit the body"
         assert self.lg_log[-7:] == ["F"] * 7 and "E" not in self.lg_log, "a body must end with its 7 fragment reads youngest"
 
     def tile_end(self):
         """Accumulators -> v[64:255] (the next tile starts with C = 0)."""
         p = self.p
+        if (self.sched.get("no_epi") and not self.sched.get("with_tile_end")) or self.sched.get("no_tile_end"):
+            return
         p.s_nop(7)
         p.s_nop(7)
         for r in range(192):
             p.v_accvgpr_read_b32(SETB[r], ACC[r])
 
     def exposed_epilogue(self):
-        epi = []
-        for t in range(12):
-            epi += self.epi_items(t)
-        for _, fn in epi:
+        if self.sched.get("no_epi"):
+            return
+        for _, _, fn in self.epi_atoms():
             fn()
 
     def kernel(self):
@@ -514,7 +611,15 @@ class ZGen:
         p.s_cmp_lg_u32(KBL, 0)
         p.s_cbranch_scc1(body_plain)
         p.label(tile_done)
-        self.tile_end()
+        if self.deferred and not self.sched.get("burst_drain"):
+            # a tile that is followed by another one is drained inside that tile's first k-step; only the last tile pays a burst
+            skip_burst = p.newlabel("noburst")
+            p.s_cmp_gt_u32(TLEFT, 1)
+            p.s_cbranch_scc1(skip_burst)
+            self.tile_end()
+            p.label(skip_burst)
+        else:
+            self.tile_end()
         # the finished tile's identity for its epilogue; then advance the tile bookkeeping
         p.s_mov_b32(PO, CUR[2])
         p.s_mov_b32(PB, CB)
@@ -590,7 +695,7 @@ def emulate(prog, A16, W16, bias, act, grid, modes=(("eager", "eager", "0123"),)
         t_b = table.view(np.uint8).reshape(-1).copy()
         ka, ptrs = make_kargs(a_b, w_b, b_b, o_b, table, M, N, K, grid)
         for bid in range(grid):
-            wg = Workgroup(prog, 4, 160 * 1024, dma_lazy=(dma == "lazy"), ds_lazy=(ds == "lazy"), order=order)
+            wg = Workgroup(prog, 4, LDS_BYTES, dma_lazy=(dma == "lazy"), ds_lazy=(ds == "lazy"), order=order)
             wg.mem_objs[(id(ka), K_A)] = {0: a_b}
             wg.mem_objs[(id(ka), K_W)] = {0: w_b}
             wg.mem_objs[(id(ka), K_BIAS)] = {0: b_b}
@@ -623,6 +728,13 @@ CLOBBERS = ([f"v{i}" for i in range(4, 256)] + [f"a{i}" for i in range(256)] + [
             ["vcc", "scc", "memory"])
 
 
+def write_meta(path):
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/kgen/gemm_z192_gen.py — do not edit.\n")
+        f.write(f"#define Z192_LDS_BYTES {LDS_BYTES}      // dynamic LDS of a launch: operand rings + bias slots + output staging\n")
+        f.write(f"#define Z192_KARG_BYTES {KARG_BYTES}\n")
+
+
 def write_inc(path, prog):
     lines = prog.text().split("\n")
     with open(path, "w") as f:
@@ -631,8 +743,33 @@ def write_inc(path, prog):
             f.write('"' + ln.replace("\\", "\\\\").replace('"', '\\"') + '\\n"\n')
 
 
+VARIANTS = {       # probe builds: tools/probes/gemm_probe variants 71..76 (ablations give wrong results)
+    1: dict(deferred=True, sched=dict(no_epi=True)),                        # k-loops only
+    2: dict(deferred=True, sched=dict(burst_drain=True)),                   # accumulators drained in one burst at the tile switch
+    3: dict(deferred=True, sched=dict(no_stage=True)),                      # drain + bias / activation / pack
+    4: dict(deferred=True, sched=dict(no_store=True)),                      # + LDS staging
+    5: dict(deferred=True, sched=dict(epi_span=8)),
+    6: dict(deferred=True, sched=dict(gap_slots=7, epi_in_dma_gaps=True)),
+}
+
+
+def variant_gen(k, act):
+    kw = VARIANTS[k]
+    sched = kw.get("sched_act1", kw["sched"]) if act == 1 else kw["sched"]
+    return ZGen(act=act, deferred=kw["deferred"], sched=sched)
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variants":
+        for k, kw in VARIANTS.items():
+            for act in (0, 1):
+                prog = variant_gen(k, act).kernel()
+                hz = check_hazards(prog)
+                assert not hz, hz[:5]
+                write_inc(os.path.join(sys.argv[2], f"z192_var{k}_act{act}.inc"), prog)
+        return
+    write_meta(os.path.join(root, "sam_road_amd", "csrc", "gemm_z192_meta.inc"))
     for act in (0, 1):
         g = ZGen(act=act, deferred=True)
         prog = g.kernel()

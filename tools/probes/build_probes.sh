@@ -5,7 +5,9 @@
 set -e
 cd "$(dirname "$0")/../.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING -Itools/probes/build"
+mkdir -p tools/probes/build
+python3 tools/kgen/gemm_z192_gen.py --variants tools/probes/build   # z192_var{1..6}_act{0,1}.inc: the schedule variants under test
 mkdir -p tools/probes/build
 for f in gemm gemm_q192 gemm_z192; do
   $HIPCC $FLAGS -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &

@@ -79,6 +79,10 @@ def reduce_canvases(kp, road, dst=0, bands=None):
     if not is_distributed():
         return
     world, rank = dist.get_world_size(), dist.get_rank()
+    if bands is not None:
+        order = [b for b in bands if b[1] > b[0]]
+        if any(order[i][0] > order[i + 1][0] for i in range(len(order) - 1)):
+            bands = None                # tile list not x-outer: the chunks are not vertical bands -> dense reduce
     if bands is None:
         both = torch.stack([kp, road])
         dist.reduce(both, dst=dst, op=dist.ReduceOp.SUM)
@@ -88,17 +92,37 @@ def reduce_canvases(kp, road, dst=0, bands=None):
         return
     if rank != dst:
         x0, x1 = bands[rank]
+        if _CHECK_BANDS[0]:
+            # a contribution outside the band would be dropped silently (an accumulate-into canvas, a tiling that is not x-outer)
+            outside = float(kp[:, :x0].abs().sum() + kp[:, x1:].abs().sum() + road[:, :x0].abs().sum() + road[:, x1:].abs().sum())
+            if outside != 0.0:
+                raise RuntimeError(f"reduce_canvases: rank {rank} holds canvas data outside its band [{x0}, {x1})")
         if x1 > x0:
             dist.send(torch.stack([kp[:, x0:x1], road[:, x0:x1]]).contiguous(), dst=dst)
         return
+    # all receives are posted at once (the senders finish pass 1 at about the same time); the bands are then added in rank order,
+    # which fixes the summation order of a pixel shared by several bands
+    parts, reqs = {}, []
     for r in range(world):
         x0, x1 = bands[r]
         if r == dst or x1 <= x0:
             continue
-        part = torch.empty((2, kp.shape[0], x1 - x0), dtype=kp.dtype, device=kp.device)
-        dist.recv(part, src=r)
-        kp[:, x0:x1] += part[0]
-        road[:, x0:x1] += part[1]
+        parts[r] = torch.empty((2, kp.shape[0], x1 - x0), dtype=kp.dtype, device=kp.device)
+        reqs.append(dist.irecv(parts[r], src=r))
+    for q in reqs:
+        q.wait()
+    for r in sorted(parts):
+        x0, x1 = bands[r]
+        kp[:, x0:x1] += parts[r][0]
+        road[:, x0:x1] += parts[r][1]
+
+
+_CHECK_BANDS = [False]       # tests switch this on: every sender checks that its canvas is zero outside its band
+
+
+def canvas_bytes(bands, S, dst=0):
+    """Bytes the banded reduce moves to `dst` for one scene (two f32 canvases, S rows)."""
+    return sum(2 * 4 * S * max(0, x1 - x0) for r, (x0, x1) in enumerate(bands) if r != dst)
 
 
 def broadcast_points(points, src=0, device=None):

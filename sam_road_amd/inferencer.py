@@ -595,8 +595,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
     multi-GPU mode instead — every scene's tiles split over the ranks through infer_one_img, one scene at a time; with
     tile_sharded=False each rank runs its own scenes through the pipeline and no collective is issued."""
     if D.is_distributed() if tile_sharded is None else tile_sharded:
-        for img in imgs:
-            yield infer_one_img(net, img, config, device)
+        yield from _infer_imgs_tile_sharded(net, imgs, config, device)
         return
     device = torch.device(device) if device is not None else next(net.parameters()).device
     lane = _Lane(device)
@@ -708,6 +707,105 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
     with _host_quiet():
         res = finish(prev)
     yield res
+
+
+def _infer_imgs_tile_sharded(net, imgs, config, device=None, stats=None):
+    """Tile-sharded scenes (BASELINE configs[3]: ONE scene's tiles over the ranks of a node), software-pipelined like infer_imgs:
+    every rank queues pass 1 of scene i+1 on its GPU BEFORE the host stages of scene i, so that rank 0's serial section (mask ->
+    graph points, reference graph_extraction.py:130-139 / graph_utils.py:572-591, and the final vote merge) runs while all GPUs —
+    its own included — are busy with the next scene's pass 1.  Per scene and rank the device then sees pass 1 / world + pass 2 /
+    world back to back; the exchange steps are the three of infer_one_img (banded canvas reduce, point broadcast, vote gather) in
+    the same order on every rank:   stage1(i+1): reduce_canvases(i+1)   |   stage2(i): broadcast_points(i), gather_*_votes(i).
+    Results per scene are those of infer_one_img under the same world size (same kernels, same summation orders); rank 0 yields
+    the tuples, the other ranks yield None.  `stats` (a dict) collects per-stage wall times and the bytes of every exchange."""
+    import time
+    device = torch.device(device) if device is not None else next(net.parameters()).device
+    world = torch.distributed.get_world_size() if D.is_distributed() else 1
+    rank = torch.distributed.get_rank() if D.is_distributed() else 0
+    bs = int(config.INFER_BATCH_SIZE)
+    cuda = device.type == "cuda"
+    stats = stats if stats is not None else {}
+    for k in ("pass1_queue_ms", "points_host_ms", "pass2_ms", "merge_host_ms", "canvas_bytes", "points_bytes", "votes_bytes", "scenes"):
+        stats.setdefault(k, 0.0)
+
+    def stage1(img):
+        job = _SceneJob()
+        t0 = time.perf_counter()
+        job.img, job.infos, job.all_xy = _scene_plan(img, config)
+        job.lo, job.hi = shard_tiles(len(job.infos), world, rank)
+        scene = torch.as_tensor(np.ascontiguousarray(job.img), dtype=torch.uint8).to(device, non_blocking=cuda)
+        job.xy_dev = torch.as_tensor(job.all_xy).to(device)
+        kp_c, road_c, job.emb = net.scene_pass1(scene, job.xy_dev[job.lo:job.hi], bs)
+        bands = D.tile_bands(job.all_xy, int(config.PATCH_SIZE), world) if world > 1 else None
+        D.reduce_canvases(kp_c, road_c, dst=0, bands=bands)
+        if bands is not None:
+            stats["canvas_bytes"] += D.canvas_bytes(bands, job.img.shape[0])
+        job.masks = job.e1 = None
+        if rank == 0:
+            kp_u8, road_u8 = net.scene_normalise(kp_c, road_c, job.xy_dev)
+            if cuda:       # asynchronous download behind the scene's own kernels: the host does not wait here
+                job.masks = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (kp_u8, road_u8)]
+                for h, t in zip(job.masks, (kp_u8, road_u8)):
+                    h.copy_(t, non_blocking=True)
+                job.e1 = torch.cuda.Event()
+                job.e1.record(torch.cuda.current_stream(device))
+            else:
+                job.masks = [kp_u8, road_u8]
+        stats["pass1_queue_ms"] += 1e3 * (time.perf_counter() - t0)
+        return job
+
+    def stage2(job):
+        t0 = time.perf_counter()
+        graph_points = kp_mask = road_mask = None
+        if rank == 0:
+            if job.e1 is not None:
+                job.e1.synchronize()
+            kp_mask, road_mask = (np.array(m.numpy() if isinstance(m, torch.Tensor) else m) for m in job.masks)
+            graph_points = extract_graph_points(kp_mask, road_mask, config)
+        t1 = time.perf_counter()
+        stats["points_host_ms"] += 1e3 * (t1 - t0)
+        graph_points = D.broadcast_points(graph_points, src=0, device=device if world > 1 else None)
+        stats["points_bytes"] += 16 * graph_points.shape[0] * (world - 1)
+        if graph_points.shape[0] == 0:
+            return None if rank != 0 else (graph_points, np.zeros((0, 2), dtype=np.int32), kp_mask, road_mask)
+        n_pts = graph_points.shape[0]
+        if world > 1 and config.EXACT_VOTE_MERGE:
+            k_raw, s_raw = edge_votes(net, job.emb, graph_points, job.infos, job.lo, job.hi, config, device, raw=True)
+            t2 = time.perf_counter()
+            stats["votes_bytes"] += 16 * k_raw.shape[0]
+            k_raw, s_raw = D.gather_raw_votes(k_raw, s_raw, dst=0, device=device)
+            if rank != 0:
+                stats["pass2_ms"] += 1e3 * (t2 - t1)
+                return None
+            uk, sums, cnts, first = _accumulate_votes(k_raw, s_raw)
+        else:
+            uk, sums, cnts, first = edge_votes(net, job.emb, graph_points, job.infos, job.lo, job.hi, config, device)
+            t2 = time.perf_counter()
+            stats["votes_bytes"] += 32 * uk.shape[0]
+            uk, sums, cnts, first = D.gather_edge_votes(uk, sums, cnts, n_pts, dst=0, device=device if world > 1 else None, first=first)
+        stats["pass2_ms"] += 1e3 * (t2 - t1)
+        job.emb = None
+        if rank != 0:
+            return None
+        t3 = time.perf_counter()
+        pred_edges = votes_to_edges(uk, sums, cnts, first, n_pts, config.TOPO_THRESHOLD)
+        stats["merge_host_ms"] += 1e3 * (time.perf_counter() - t3)
+        return graph_points[:, ::-1], pred_edges, kp_mask, road_mask
+
+    it = iter(imgs)
+    img = next(it, None)
+    if img is None:
+        return
+    with _host_quiet():
+        cur = stage1(img)
+    while cur is not None:
+        with _host_quiet():
+            img = next(it, None)
+            nxt = stage1(img) if img is not None else None        # the next scene's pass 1 is on the device before this scene's host work
+            res = stage2(cur)
+        stats["scenes"] += 1
+        yield res
+        cur = nxt
 
 
 def get_img_paths(root_dir, image_indices):

@@ -322,3 +322,72 @@ def test_cli_scene_sharding_world2(tmp_path):
         gr = pickle.load(open(outdir / "graph" / f"{i}.p", "rb"))
         assert (int(src[0, 0, 0]), 7) in gr
     assert open(outdir / "inference_time.txt").read().startswith("Inference completed for cfg.yaml in ")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Tile-sharded scenes, software-pipelined (inferencer._infer_imgs_tile_sharded: pass 1 of scene i+1 is queued before the host
+# stages of scene i; the band receives are posted at once): world 8 on gloo against the single-process results.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _pipe_run(world, rank, port, out, scene_size, overrides, seeds):
+    import warnings
+    warnings.simplefilter("ignore")
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.synth import synth_scene
+        from sam_road_amd import Config
+        from sam_road_amd import distributed as D
+        from sam_road_amd.inferencer import _infer_imgs_tile_sharded, infer_imgs, infer_one_img
+        torch.set_num_threads(1)
+        D._CHECK_BANDS[0] = True                  # every sender asserts that its canvas is zero outside the band it ships
+        cfg = dict(_E2E_CFG, **(overrides or {}))
+        net = _CpuStandIn(cfg)
+        imgs = [synth_scene(scene_size, seed=s) if s >= 0 else np.zeros((scene_size, scene_size, 3), np.uint8) for s in seeds]
+        stats = {}
+        if world > 1:
+            got = list(_infer_imgs_tile_sharded(net, iter(imgs), Config(cfg), device="cpu", stats=stats))
+            assert list(infer_imgs(net, iter([]), Config(cfg), device="cpu", tile_sharded=True)) == []
+        else:
+            got = [infer_one_img(net, im, Config(cfg), device="cpu") for im in imgs]
+        out.put((rank, [None if r is None else [np.asarray(a) for a in r] for r in got], stats))
+    except Exception:  # pragma: no cover
+        import traceback
+        out.put((rank, "ERR " + traceback.format_exc(), None))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_pipelined_tile_sharded_scenes_world8_match_single_process():
+    """Three scenes (one of them all-zero pixels) through the pipelined tile-sharded generator on 8 ranks — more ranks than
+    tiles, so half of them own an empty shard and an empty band — with disjoint tiles (every canvas pixel has one addend: the
+    results must be IDENTICAL to the single-process run, edges in the same order)."""
+    ctx = mp.get_context("spawn")
+    overrides = dict(SAMPLE_MARGIN=0, INFER_PATCHES_PER_EDGE=2)
+    seeds = [6, -1, 9]
+    results = {}
+    for world in (1, 8):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_pipe_run, args=(world, r, port, q, 512, overrides, seeds)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = {}
+        for _ in range(world):
+            r, v, st = q.get(timeout=900)
+            assert not isinstance(v, str), v
+            got[r] = (v, st)
+        for p in procs:
+            p.join(timeout=60)
+        for r, (v, st) in got.items():
+            assert all((x is None) == (r != 0) for x in v)                   # only rank 0 yields the graphs
+        results[world] = got[0]
+    one, (eight, stats) = results[1][0], results[8]
+    assert len(one) == len(eight) == 3 and one[0][0].shape[0] > 30 and one[2][1].shape[0] > 100
+    for a, b in zip(one, eight):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+            assert x.dtype == y.dtype
+    assert stats["scenes"] == 3 and stats["canvas_bytes"] > 0 and stats["points_bytes"] > 0 and stats["votes_bytes"] >= 0

@@ -391,3 +391,28 @@ def test_pipelined_tile_sharded_scenes_world8_match_single_process():
             np.testing.assert_array_equal(x, y)
             assert x.dtype == y.dtype
     assert stats["scenes"] == 3 and stats["canvas_bytes"] > 0 and stats["points_bytes"] > 0 and stats["votes_bytes"] >= 0
+
+
+def test_bench_launch_contract_two_ranks_on_cpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --plumbing-cpu`: the driver's multi-GPU launch
+    line on gloo / CPU with the oracle stand-in — rank / world / master address from the environment, collectives connect both
+    ranks, rank 0 prints ONE JSON line; the tile-sharded scenes equal the one-process run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--plumbing-cpu"]
+        if n > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port())] + cmd[1:]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        js = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1, r.stdout
+        lines[n] = js[0]
+    assert lines[2]["collective_ranks"] == 2 and lines[2]["n_gpus"] == 2 and lines[2]["plumbing_only"] and lines[2]["value"] is None
+    assert lines[1]["graph_points"] == lines[2]["graph_points"] and lines[1]["edges"] == lines[2]["edges"]
+    assert len(lines[2]["per_rank"]) == 2 and lines[2]["per_rank"][1][1] > 0        # rank 1 shipped canvas bytes

@@ -642,8 +642,11 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     }
     if (variant == 1) return launch_cfg<0, 2, 2, 2, 2>(p, stream);
     if (variant == 2 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<0, 4, 2, 2, 4>(p, stream);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // dynamic-LDS opt-in is per device (a function attribute lives in the device's code object): one bit per device
+    static unsigned attr_set = 0;
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!(attr_set & (1u << (dev_ & 31)))) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -652,7 +655,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr_set = true;
+        attr_set |= 1u << (dev_ & 31);
     }
     // 256x256 tiles halve the L2->LDS traffic per FLOP but there are only 256 CUs: use them when the tile
     // count fills the chip evenly (<= one round, or >= 80 % occupancy of the last round), else 128x128.
@@ -670,8 +673,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const bool t160 = variant == 0 && use_tile160(p);
-    const int want160 = t160 ? gemm_splitk_factor(p) : 1;      // 1, or 4 when the 160-wide tiles only fill the chip with split-K
-    if ((t160 && (want160 == 1 || (p.split_ws && p.splitk == want160))) || variant == 30 || variant == 31) {
+    if (t160 || variant == 30 || variant == 31) {        // (gemm_splitk_factor is 1 whenever use_tile160 holds: one round of 160-wide tiles)
         // variant 30 / 31 (probe): force the 160-wide tiles without / with split-K (31 needs p.split_ws and p.splitk)
         const int sk = p.split_ws && p.splitk > 1 && variant != 30 ? p.splitk : 1;
         if (p.N % 160 != 0) return -2;

@@ -437,8 +437,10 @@ bool q192_supported(const GemmParams& p) {
 
 template <int ACT, bool BIAS>
 static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int ablation) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;        // per device (one bit each), per template instantiation
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!(attr_set & (1u << (dev_ & 31)))) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
 #ifdef SRH_TUNING      // ablation / schedule variants: probe builds only (tools/probes/build_probes.sh); several of them change the RESULT
@@ -451,7 +453,7 @@ static void q192_launch(const GemmParams& p, hipStream_t stream, int grid, int a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<3, ACT, BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q192_kernel<0, ACT, BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
 #endif
-        attr_set = true;
+        attr_set |= 1u << (dev_ & 31);
     }
 #ifdef SRH_TUNING
     if (ablation == 1) { hipLaunchKernelGGL((gemm_q192_kernel<1, ACT, BIAS, 0>), dim3(grid), dim3(512), Q_LDS, stream, p); return; }

@@ -50,7 +50,4 @@ def worker_threads(cap=8):
 def fill_threads(cap=16):
     """Thread count for srh_pass2_fill, the one host stage with tens of milliseconds of CPU work per scene (kNN of ~50k query rows):
     every usable CPU of this rank's share, at most `cap` (measured on a 16-CPU quota: 23.4 ms on one thread, 4.3 on 8, 2.8 on 16)."""
-    env = os.environ.get("SRH_FILL_THREADS")          # tuning aid
-    if env:
-        return max(1, int(env))
     return max(1, min(cap, usable_cpus() // ranks_on_this_host()))

@@ -60,6 +60,39 @@ class _FlatQueries:
         return self.ids[a:b], self.local[a:b], pairs, valid
 
 
+_KDTREE_OK = [None]      # None: not checked yet; True / False: the library's kd-tree restatement agrees with the installed scipy
+
+
+def _kdtree_selfcheck():
+    """csrc/kdtree_emul.hpp restates how scipy's kd-tree (validated against scipy 1.15) breaks ties at the k-th neighbour.  Another
+    scipy build could break them differently with no signal, so the first call compares the two on a small lattice where almost
+    every row is tied (one tile, 13 x 11 points 8 px apart plus duplicates); on a mismatch the per-tile scipy path answers from
+    then on — the reference's own call, slower — and a warning names the installed version."""
+    if _KDTREE_OK[0] is not None:
+        return _KDTREE_OK[0]
+    _KDTREE_OK[0] = True                                        # re-entrancy guard: the check itself goes through the library path
+    xs, ys = np.meshgrid(np.arange(13) * 8 + 3, np.arange(11) * 8 + 5)
+    pts = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int64)
+    pts = np.concatenate([pts, pts[[5, 5, 40, 77]]], 0)         # coincident points as well
+    cfg = type("C", (), dict(MAX_NEIGHBOR_QUERIES=16, NEIGHBOR_RADIUS=64))()
+    infos = [(0, (0, 0), (127, 127))]
+    try:
+        want = build_patch_queries(pts, 0, 0, 127, 127, cfg)
+        got = build_all_patch_queries(pts, infos, 0, 1, cfg)[0]
+        # the SET of neighbours of every source point must be scipy's (which points fall on the kept side of a tie); the order inside a
+        # group of equidistant neighbours is heap-internal in scipy and (distance, index) in the library — the edge vote does not see it
+        nbr = lambda q: np.sort(np.where(q[3], q[2][..., 1], -1), axis=1)
+        ok = np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]) and np.array_equal(nbr(want), nbr(got))
+    except Exception:
+        ok = False
+    if not ok:
+        import warnings
+        warnings.warn(f"the kd-tree tie-breaking restated in libsamroad_hip (validated against scipy 1.15) differs from the installed scipy "
+                      f"{scipy.__version__}: pass-2 queries fall back to the per-tile scipy path", RuntimeWarning)
+    _KDTREE_OK[0] = ok
+    return ok
+
+
 def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     """build_patch_queries for tiles [lo, hi) in ONE call into the library's host code (srh_pass2_count / srh_pass2_fill,
     csrc/host_geom.hip: closed-box filter + exact integer kNN per tile, worker threads).  Source points whose scipy result is
@@ -74,7 +107,7 @@ def build_all_patch_queries(graph_points, infos, lo, hi, config, flat=False):
     n_tiles = hi - lo
     if n_tiles <= 0:
         return None if flat else []
-    if float(r) != int(r) or not np.issubdtype(graph_points.dtype, np.integer):
+    if float(r) != int(r) or not np.issubdtype(graph_points.dtype, np.integer) or not _kdtree_selfcheck():
         if flat:
             return None
         return [build_patch_queries(graph_points, *infos[t][1], *infos[t][2], config) for t in range(lo, hi)]
@@ -121,9 +154,11 @@ def _collate(xs):
     return out
 
 
+PASS2_SORT_TILES = True       # False: batches of consecutive tiles, as the reference forms them (tools / tests set it; no environment switch)
+
+
 def _sort_pass2_tiles():
-    import os
-    return os.environ.get("SRH_PASS2_SORT", "1") != "0"          # tuning aid: 0 = batches of consecutive tiles, as the reference forms them
+    return PASS2_SORT_TILES
 
 
 def _pass2_plan(fq, bs, sort_tiles=None):
@@ -190,7 +225,12 @@ def _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, lo=0):
     out = []
     for tiles, n_max, base in plan:
         nb, sl = len(tiles), slice(base, base + len(tiles) * n_max)
-        e = emb[int(tiles[0]):int(tiles[-1]) + 1] if _contiguous(tiles) else emb.index_select(0, torch.as_tensor(tiles, device=emb.device))
+        if _contiguous(tiles):
+            e = emb[int(tiles[0]):int(tiles[-1]) + 1]
+        else:
+            # emb is an NCHW view of channels-last memory ([B,h,w,256] is what the library wrote and what srh_toponet reads): gather in
+            # the STORAGE layout — index_select on the view would write an NCHW-contiguous copy that _topo then copies back
+            e = emb.permute(0, 2, 3, 1).index_select(0, torch.as_tensor(tiles, device=emb.device)).permute(0, 3, 1, 2)
         scores = net.infer_toponet(e, pts_d[sl].view(nb, n_max, 2), pairs_d[sl].view(nb, n_max, K, 2), valid_d[sl].view(nb, n_max, K))
         out.append((tiles, torch.where(torch.isnan(scores), -100.0, scores).squeeze(-1)))
     return out

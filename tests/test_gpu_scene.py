@@ -117,3 +117,26 @@ def test_infer_imgs_pipeline_equals_serial(pair):
         for w, g in zip(want, got):
             for a, b in zip(w, g):
                 np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_pass2_batching_sorted_vs_consecutive(pair):
+    """TopoNet batches of tiles grouped by row count (the default: non-contiguous tiles, embeddings gathered in their storage
+    layout) against batches of consecutive tiles (the reference's): every tile's rows are scored independently of its batch
+    mates, so the pipeline must yield the same nodes, the same masks and the same edges in the same order."""
+    from sam_road_amd import Config
+    from sam_road_amd import inferencer as inf
+    _, net = pair
+    cfg = Config(CFG)
+    imgs = [synth_scene(SCENE, seed=21), synth_scene(SCENE, seed=22)]
+    assert inf.PASS2_SORT_TILES
+    try:
+        got = {}
+        for flag in (True, False):
+            inf.PASS2_SORT_TILES = flag
+            got[flag] = list(inf.infer_imgs(net, iter(imgs), cfg, tile_sharded=False))
+    finally:
+        inf.PASS2_SORT_TILES = True
+    assert got[True][0][0].shape[0] > 30 and got[True][0][1].shape[0] > 100
+    for a, b in zip(got[True], got[False]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y))

@@ -363,34 +363,54 @@ class ZGen:
                         e_ = [GT[3 * e + 1] for e in range(4)]
                         m_ = [GT[3 * e + 2] for e in range(4)]
 
+                        gd = self.sched.get("gelu_dummy", 0)     # probe: 1 = every GELU instruction becomes a v_mov, 2 = only the v_exp does
+
                         def f1(es, x=x, r_=r_):
                             for e in es:
-                                p.v_fma_f32(r_[e], VC0, vabs(x[e]), GC[0])
+                                if gd == 1:
+                                    p.v_mov_b32(r_[e], x[e])
+                                else:
+                                    p.v_fma_f32(r_[e], VC0, vabs(x[e]), GC[0])
                         atom_halves(f1)
                         for c in (1, 2, 3):
                             def f2(es, x=x, r_=r_, c=c):
                                 for e in es:
-                                    p.v_fma_f32(r_[e], r_[e], vabs(x[e]), GC[c])
+                                    if gd == 1:
+                                        p.v_mov_b32(r_[e], x[e])
+                                    else:
+                                        p.v_fma_f32(r_[e], r_[e], vabs(x[e]), GC[c])
                             atom_halves(f2)
 
                         def f5(es, x=x, r_=r_):
                             for e in es:
-                                p.v_fma_f32(r_[e], r_[e], vabs(x[e]), 1.0)
+                                if gd == 1:
+                                    p.v_mov_b32(r_[e], x[e])
+                                else:
+                                    p.v_fma_f32(r_[e], r_[e], vabs(x[e]), 1.0)
                         atom_halves(f5)
 
                         def fe(es, r_=r_, e_=e_):
                             for e in es:
-                                p.v_exp_f32(e_[e], neg(r_[e]))                       # 2^-r
+                                if gd:
+                                    p.v_mov_b32(e_[e], r_[e])
+                                else:
+                                    p.v_exp_f32(e_[e], neg(r_[e]))                   # 2^-r
                         atom_halves(fe)
 
                         def fm(es, x=x, m_=m_):
                             for e in es:
-                                p.v_max_f32(m_[e], 0, x[e])                          # max(x, 0)
+                                if gd == 1:
+                                    p.v_mov_b32(m_[e], x[e])
+                                else:
+                                    p.v_max_f32(m_[e], 0, x[e])                      # max(x, 0)
                         atom_halves(fm)
 
                         def fo(es, x=x, e_=e_, m_=m_):
                             for e in es:
-                                p.v_fma_f32(x[e], nabs(x[e]), e_[e], m_[e])          # max(x,0) - |x| 2^-r
+                                if gd == 1:
+                                    p.v_mov_b32(x[e], m_[e])
+                                else:
+                                    p.v_fma_f32(x[e], nabs(x[e]), e_[e], m_[e])      # max(x,0) - |x| 2^-r
                         atom_halves(fo)
                 for q in range(4):
                     def pack(B=B, q=q):
@@ -743,13 +763,14 @@ def write_inc(path, prog):
             f.write('"' + ln.replace("\\", "\\\\").replace('"', '\\"') + '\\n"\n')
 
 
-VARIANTS = {       # probe builds: tools/probes/gemm_probe variants 71..76 (ablations give wrong results)
+VARIANTS = {       # probe builds: tools/probes/gemm_probe variants 71..76 (ablations give wrong results).  The sets measured in round 4
+    # (profiles/r04_z192_*.txt) were edited here between runs; this is the last one: what does a deferred epilogue cost, step by step?
     1: dict(deferred=True, sched=dict(no_epi=True)),                        # k-loops only
     2: dict(deferred=True, sched=dict(burst_drain=True)),                   # accumulators drained in one burst at the tile switch
-    3: dict(deferred=True, sched=dict(no_stage=True)),                      # drain + bias / activation / pack
+    3: dict(deferred=True, sched=dict(no_stage=True)),                      # drain + bias / activation / pack, nothing leaves
     4: dict(deferred=True, sched=dict(no_store=True)),                      # + LDS staging
-    5: dict(deferred=True, sched=dict(epi_span=8)),
-    6: dict(deferred=True, sched=dict(gap_slots=7, epi_in_dma_gaps=True)),
+    5: dict(deferred=True, sched=dict(gelu_dummy=1)),                       # the product schedule with every GELU instruction a v_mov
+    6: dict(deferred=False, sched=dict()),                                  # exposed epilogue after every tile
 }
 
 

@@ -721,15 +721,15 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
     // write their branch output (bias included) as fp16 into delta16 and the NEXT LayerNorm pass folds "x += delta" into
     // its read of x — the same HBM bytes as the GEMM-epilogue residual add, but moved out of the GEMM's exposed epilogue
     // into a streaming kernel.  Otherwise the GEMM epilogue adds the residual itself.
-    static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
+    const bool use_q192 = true;
     // When BOTH branch GEMMs of a block go through q192, the attention branch (delta16) is not written back to x by the second
     // LayerNorm — it only normalises x + delta16 — and the next block's first LayerNorm folds both branches, (x + delta16) +
     // delta16b, and writes x once per block: 275 instead of 300 MB of LayerNorm traffic per block at B = 16, same sums in the
     // same order bit for bit.
     bool pend_a = false, pend_b = false;                  // delta16 (proj) / delta16b (fc2) hold a branch output not yet added to x
-    auto branch_gemm = [&](const char* cls, const f16* A, int lda, const f16* W, int K, const float* bias, bool second) -> int {
+    auto branch_gemm = [&](const char* cls, const f16* A, int lda, const f16* W, int K, const float* bias, bool second, int a_blocked = 0) -> int {
         GemmParams gq;
-        gq.A = A; gq.lda = lda; gq.W = W; gq.ldw = K; gq.M = T; gq.N = D; gq.K = K; gq.bias = bias;
+        gq.A = A; gq.lda = lda; gq.W = W; gq.ldw = K; gq.M = T; gq.N = D; gq.K = K; gq.bias = bias; gq.a_blocked16 = a_blocked;
         gq.out_f16 = second ? c->delta16b.as<f16>() : c->delta16.as<f16>(); gq.ldc16 = D;
         if (use_q192 && q192_preferred(gq)) { (second ? pend_b : pend_a) = true; return gemm(c, cls, gq, s); }
         GemmParams gp = gq;
@@ -777,8 +777,19 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         GemmParams g1;
         g1.A = c->xn16.as<f16>(); g1.lda = D; g1.W = b.fc1_w; g1.ldw = D; g1.M = T; g1.N = 4 * D; g1.K = D;
         g1.bias = b.fc1_b; g1.act = 1; g1.out_f16 = c->hid16.as<f16>(); g1.ldc16 = 4 * D;
+        // the hidden activation lives only between these two launches: when both take gemm_z192 it is kept in the blocked-16 layout
+        // (fc1 stores 1 KiB contiguous per instruction, no LDS transposition; fc2's LDS-DMA reads it through per-lane addresses)
+        int hid_blocked = 0;
+        {
+            GemmParams t1 = g1, t2;
+            t1.out_blocked16 = 1;
+            t2.A = c->hid16.as<f16>(); t2.lda = 4 * D; t2.W = b.fc2_w; t2.ldw = 4 * D; t2.M = T; t2.N = D; t2.K = 4 * D; t2.bias = b.fc2_b;
+            t2.out_f16 = c->delta16b.as<f16>(); t2.ldc16 = D; t2.a_blocked16 = 1;
+            hid_blocked = q192_preferred(g1) && z192_supported(t1) && q192_preferred(t2) && z192_supported(t2);
+        }
+        g1.out_blocked16 = hid_blocked;
         TRY(gemm(c, "gemm_fc1", g1, s));
-        TRY(branch_gemm("gemm_fc2", c->hid16.as<f16>(), 4 * D, b.fc2_w, 4 * D, b.fc2_b, true));
+        TRY(branch_gemm("gemm_fc2", c->hid16.as<f16>(), 4 * D, b.fc2_w, 4 * D, b.fc2_b, true, hid_blocked));
     }
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d  (channels-last: LN2d is a row LN)
     {

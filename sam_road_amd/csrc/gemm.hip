@@ -630,8 +630,11 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     const int variant = 0;
 #endif
     // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
-    static const bool use_q192 = !(getenv("SRH_GEMM_Q192") && atoi(getenv("SRH_GEMM_Q192")) == 0);
-    if (variant == 0 && use_q192 && q192_preferred(p)) {
+    if (p.a_blocked16 || p.out_blocked16) {     // only gemm_z192 understands the blocked-16 layout
+        if (variant == 0 && q192_preferred(p) && z192_supported(p)) return launch_gemm_z192(p, stream);
+        return -2;
+    }
+    if (variant == 0 && q192_preferred(p)) {
         // hand-scheduled successor (gemm_z192.hip) wherever it applies (bias, no activation / GELU); q192 keeps the rest
 #ifdef SRH_TUNING
         static const bool use_z192 = !(getenv("SRH_GEMM_Z192") && atoi(getenv("SRH_GEMM_Z192")) == 0);    // probe builds: A/B against q192

@@ -82,8 +82,16 @@ GELU_C = [0.00048291164585022967, -0.0071898452371611365, 0.05218537922649359, 0
 
 
 class ZGen:
-    def __init__(self, act=0, deferred=True, sched=None):
+    """out_blocked / a_blocked: the fp16 matrix between fc1 and fc2 (the MLP's hidden activation, the largest tensor of a block) in
+    the BLOCKED-16 layout instead of row-major: element (m, n) at byte  ((m/32) * (N/16) + n/16) * 1024 + ((n%16)/8) * 512 +
+    (m%32) * 16 + (n%8) * 2,  i.e. 1 KiB blocks of 32 rows x 16 columns, each holding the two 16-byte chunks of its rows
+    chunk-major.  That is exactly what one epilogue store instruction holds after the half-wave exchange (lane = 32 * chunk + row),
+    so fc1 stores 1 KiB CONTIGUOUS per instruction — no LDS transposition, the cheapest store the address path knows — and fc2's
+    LDS-DMA pieces (8 rows x 8 chunks) still touch 8 full 128-byte lines, only through different per-lane addresses."""
+
+    def __init__(self, act=0, deferred=True, sched=None, out_blocked=False, a_blocked=False):
         self.act, self.deferred = act, deferred
+        self.out_blocked, self.a_blocked = out_blocked, a_blocked
         self.p = Prog()
         self.sched = sched or {}
 
@@ -126,8 +134,23 @@ class ZGen:
         p.v_xor_b32(t1, t1, t2)                           # swizzled chunk
         p.v_mul_lo_u32(t2, t0, LDW)
         p.v_lshl_add_u32(VW, t1, 4, t2)
-        p.v_mul_lo_u32(t2, t0, LDA)
-        p.v_lshl_add_u32(VX, t1, 4, t2)
+        if self.a_blocked:
+            # blocked-16 A operand.  In memory the 8 rows of a piece are contiguous for ONE 16-byte chunk column (128 B) and chunk
+            # columns are 512 B apart, so the lanes that share a 128-byte line must be CONSECUTIVE lanes (the address path merges
+            # neighbours only: with the row-major lane order — 8 chunks of one row in 8 consecutive lanes — the same piece cost
+            # 64 separate 16-byte requests and fc2 ran 22 us slower).  Lane l therefore moves chunk position l>>3 of row l&7, the
+            # LDS image of an X piece is chunk-major (position*128 + row*16), and the XOR swizzle that keeps the fragment
+            # ds_read_b128 conflict-free is one bit: position p holds chunk p ^ (piece & 1), piece & 1 = wave & 1 for every piece of a wave.
+            p.s_and_b32(T0, WAVE, 1)
+            p.v_lshrrev_b32(t2, 3, LANE)
+            p.v_xor_b32(t2, T0, t2)                       # chunk = (lane >> 3) ^ (wave & 1)
+            p.v_lshlrev_b32(t2, 9, t2)                    # * 512
+            p.v_and_b32(t3, 7, LANE)
+            p.v_lshl_add_u32(t3, WAVE, 3, t3)             # row & 31 = wave*8 + (lane & 7)
+            p.v_lshl_add_u32(VX, t3, 4, t2)
+        else:
+            p.v_mul_lo_u32(t2, t0, LDA)
+            p.v_lshl_add_u32(VX, t1, 4, t2)
         # fragment addresses: frow = lane&31, fhalf = lane>>5, key = (frow>>1)&7
         p.v_and_b32(t0, 31, LANE)                         # frow
         p.v_lshrrev_b32(t1, 5, LANE)                      # fhalf
@@ -144,39 +167,60 @@ class ZGen:
             p.v_xor_b32(c, c, t2)
             p.v_lshl_add_u32(c, c, 4, t3)                 # ((2ks+fhalf)^key)*16 + frow*128
             p.v_add_u32(WF[ks], T2, c)
+            if self.a_blocked:
+                # chunk-major X image: piece (frow >> 3) of the 32-row block at +1024 each, position ((2ks + fhalf) ^ (piece & 1)) * 128, row (frow & 7) * 16
+                c = TMP[5]
+                p.v_lshrrev_b32(c, 3, t0)
+                p.v_and_b32(TMP[6], 1, c)
+                p.v_lshlrev_b32(c, 10, c)                 # (frow >> 3) * 1024
+                p.v_or_b32(TMP[7], 2 * ks, t1)
+                p.v_xor_b32(TMP[7], TMP[7], TMP[6])
+                p.v_lshl_add_u32(c, TMP[7], 7, c)
+                p.v_and_b32(TMP[7], 7, t0)
+                p.v_lshl_add_u32(c, TMP[7], 4, c)
             for slot in range(3):
                 p.v_add_u32(XF[slot * 4 + ks], T3, c)
                 p.v_add_u32(XF[slot * 4 + ks], X_BASE + slot * X_SLOT, XF[slot * 4 + ks])
-        # output staging (per wave, STG_LDS + wave*STG_WAVE): 32 rows x 112 B.  After the half-wave exchange a lane holds 16
-        # contiguous bytes of its row: lanes 0-31 the first, lanes 32-63 the second 8 columns of a 16-column group.
-        p.s_mul_i32(T2, WAVE, STG_WAVE)
-        p.s_add_u32(T2, T2, STG_LDS)                      # wave's staging base
-        p.s_mov_b32(KBL, STG_ROW)                         # VOP3 takes no literal on gfx9: constants through (idle) SGPRs
-        p.v_mul_lo_u32(t3, t0, KBL)                       # frow * 112
-        p.v_lshl_add_u32(t3, t1, 4, t3)                   # + fhalf*16
-        p.v_add_u32(VS, T2, t3)
-        # read-back: lane + 64 r = 6 * row + seg  (32 rows x 6 segments of 16 B = 3 KiB)
-        p.s_lshl_b32(T3, T1, 7)                           # wm * 128
-        p.s_mul_i32(T3, T3, LDC)
-        p.s_mul_i32(T0, T0, 192)                          # wn * 192   (T0 held wn)
-        p.s_add_u32(T3, T3, T0)
-        p.s_mov_b32(T1, 43691)
-        for r in range(3):
-            idx, row, seg = TMP[6], TMP[7], TMP[8]
-            p.v_add_u32(idx, 64 * r, LANE)
-            p.v_mul_lo_u32(row, idx, T1)
-            p.v_lshrrev_b32(row, 18, row)                  # idx // 6 (43691 / 2^18; exact for idx < 2^15)
-            p.v_mul_lo_u32(seg, row, 6)
-            p.v_sub_u32(seg, idx, seg)
-            p.v_lshlrev_b32(seg, 4, seg)
-            p.v_mul_lo_u32(idx, row, KBL)
-            p.v_add_u32(idx, idx, seg)
-            p.v_add_u32(VR[r], T2, idx)
-            p.v_mul_lo_u32(idx, row, LDC)
-            p.v_add_u32(idx, idx, seg)
-            p.v_add_u32(VGO[r], T3, idx)
+        if self.out_blocked:
+            # blocked-16 output: a store instruction writes 1 KiB contiguous, lane * 16 inside it; the wave's block offset
+            # (wm * 4 row blocks, wn * 6 column pairs) goes into T1 for good
+            p.v_lshlrev_b32(VS, 4, LANE)
+            p.s_lshl_b32(T3, LDC, 5)                          # one row block of 32 rows = N/16 KiB = 32 * ldc2
+            p.s_mul_i32(T3, T3, T1)                           # wm * ...
+            p.s_lshl_b32(T3, T3, 2)                           # ... * 4 row blocks
+            p.s_mul_i32(T1, T0, 6144)                         # wn * 6 column pairs
+            p.s_add_u32(T1, T1, T3)
+        else:
+            # output staging (per wave, STG_LDS + wave*STG_WAVE): 32 rows x 112 B.  After the half-wave exchange a lane holds 16
+            # contiguous bytes of its row: lanes 0-31 the first, lanes 32-63 the second 8 columns of a 16-column group.
+            p.s_mul_i32(T2, WAVE, STG_WAVE)
+            p.s_add_u32(T2, T2, STG_LDS)                      # wave's staging base
+            p.s_mov_b32(KBL, STG_ROW)                         # VOP3 takes no literal on gfx9: constants through (idle) SGPRs
+            p.v_mul_lo_u32(t3, t0, KBL)                       # frow * 112
+            p.v_lshl_add_u32(t3, t1, 4, t3)                   # + fhalf*16
+            p.v_add_u32(VS, T2, t3)
+            # read-back: lane + 64 r = 6 * row + seg  (32 rows x 6 segments of 16 B = 3 KiB)
+            p.s_lshl_b32(T3, T1, 7)                           # wm * 128
+            p.s_mul_i32(T3, T3, LDC)
+            p.s_mul_i32(T0, T0, 192)                          # wn * 192   (T0 held wn)
+            p.s_add_u32(T3, T3, T0)
+            p.s_mov_b32(T1, 43691)
+            for r in range(3):
+                idx, row, seg = TMP[6], TMP[7], TMP[8]
+                p.v_add_u32(idx, 64 * r, LANE)
+                p.v_mul_lo_u32(row, idx, T1)
+                p.v_lshrrev_b32(row, 18, row)                  # idx // 6 (43691 / 2^18; exact for idx < 2^15)
+                p.v_mul_lo_u32(seg, row, 6)
+                p.v_sub_u32(seg, idx, seg)
+                p.v_lshlrev_b32(seg, 4, seg)
+                p.v_mul_lo_u32(idx, row, KBL)
+                p.v_add_u32(idx, idx, seg)
+                p.v_add_u32(VR[r], T2, idx)
+                p.v_mul_lo_u32(idx, row, LDC)
+                p.v_add_u32(idx, idx, seg)
+                p.v_add_u32(VGO[r], T3, idx)
         p.s_lshl_b32(LDC16, LDC, 5)
-        p.s_sub_u32(LDC16, LDC16, 96)                     # store offset step between row blocks: 32 rows on, 96 B back
+        p.s_sub_u32(LDC16, LDC16, 5120 if self.out_blocked else 96)     # store offset step between row blocks: 32 rows on, 5 KiB / 96 B back
         for k in range(4):
             p.s_mov_b32(GC[k], float(GELU_C[k + 1]))
         p.s_and_b32(T0, WAVE, 1)                          # wn again (T0 was reused)
@@ -268,13 +312,13 @@ class ZGen:
                 p.buffer_load_lds(16, VX, RS_X, TX)
                 self.vm_log.append("X")
                 if q == 7 and advance:
-                    self.advance(DX, DXL, NXT[0])
+                    self.advance(DX, DXL, NXT[0], 4096 if self.a_blocked else 128)
             out.append(emit)
         return out
 
-    def advance(self, d, left, nxt_off):
+    def advance(self, d, left, nxt_off, step=128):
         p = self.p
-        p.s_add_u32(d, d, 128)
+        p.s_add_u32(d, d, step)
         p.s_sub_u32(left, left, 1)
         p.s_cmp_eq_u32(left, 0)
         p.s_cselect_b32(d, nxt_off, d)
@@ -425,6 +469,28 @@ class ZGen:
             if self.sched.get("no_stage"):
                 continue
             nt = bool(self.sched.get("store_nt"))
+            if self.out_blocked:
+                for i in range(3):
+                    B = SETB.sub(16 * (4 * i + j), 16)
+                    for kp in range(2):
+                        def sw(B=B, kp=kp):
+                            p.s_nop(1)                                # VALU write -> v_permlane32_swap: 2 wait states
+                            for d in range(2):
+                                p.v_permlane32_swap_b32(B[4 * kp + d], B[4 * kp + 2 + d])
+                        atom(2, "valu", sw)
+
+                        def st(B=B, kp=kp, i=i, j=j):
+                            if j == 0 and i == 0 and kp == 0:
+                                p.s_add_u32(T2, PO, T1)
+                            elif i == 0 and kp == 0:
+                                p.s_add_u32(T2, T2, LDC16)            # next row block
+                            else:
+                                p.s_add_u32(T2, T2, 1024)
+                            if not self.sched.get("no_store"):
+                                p.buffer_store_dwordx4(B.sub(4 * kp, 4), VS, RS_O, T2, nt=nt)
+                                self.vm_log.append("S")
+                        atom(2, "vmem", st)
+                continue
             groups = [[(0, 0), (0, 1), (1, 0)], [(1, 1), (2, 0), (2, 1)]]          # (W block i, column-group pair kp) per half
             for c in range(2):
                 for g, (i, kp) in enumerate(groups[c]):
@@ -668,7 +734,18 @@ class ZGen:
 
 
 # ---------------------------------------------------------------------------------------------- host-side helpers
-def tile_table(M, N, lda, ldw, ldc, grid=None, GR=4):
+def to_blocked16(a):
+    """Row-major fp16 [M, N] -> the blocked-16 layout (ZGen docstring), as a flat array of the same size."""
+    M, N = a.shape
+    assert M % 32 == 0 and N % 16 == 0
+    return np.ascontiguousarray(a.reshape(M // 32, 32, N // 16, 2, 8).transpose(0, 2, 3, 1, 4)).reshape(-1)
+
+
+def from_blocked16(flat, M, N):
+    return np.ascontiguousarray(flat.reshape(M // 32, N // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4)).reshape(M, N)
+
+
+def tile_table(M, N, lda, ldw, ldc, grid=None, GR=4, out_blocked=False):
     """XCD-aware persistent tile order (the order gemm_q192 uses): virtual block vb runs on XCD vb % 8; every XCD owns a
     contiguous run of the tile order; tiles are ordered in groups of GR tile rows with the column index outer.
     Returns int32 [ntiles, 4] = {x_off, w_off, out_off, bias_off} in bytes, indexed by vb (the workgroup reads
@@ -686,7 +763,7 @@ def tile_table(M, N, lda, ldw, ldc, grid=None, GR=4):
         gsz = min(GR, tiles_m - first_m)
         m0 = (first_m + within % gsz) * 256
         n0 = (within // gsz) * 192
-        tab[vb] = (m0 * lda * 2, n0 * ldw * 2, (m0 * ldc + n0) * 2, n0 * 4)
+        tab[vb] = (m0 * lda * 2, n0 * ldw * 2, (m0 * ldc * 2 + n0 * 64) if out_blocked else (m0 * ldc + n0) * 2, n0 * 4)
     return tab
 
 
@@ -699,16 +776,17 @@ def make_kargs(A_, W_, bias, out, table, M, N, K, grid):
     return ka, ptrs
 
 
-def emulate(prog, A16, W16, bias, act, grid, modes=(("eager", "eager", "0123"),), verbose=False):
-    """Run the generated kernel on numpy operands for every mode tuple (dma, ds, wave order); returns the fp16 outputs."""
+def emulate(prog, A16, W16, bias, act, grid, modes=(("eager", "eager", "0123"),), verbose=False, out_blocked=False, a_blocked=False):
+    """Run the generated kernel on numpy operands for every mode tuple (dma, ds, wave order); returns the fp16 outputs
+    (row-major [M, N] whatever layout the kernel wrote; A16 is given row-major and re-laid-out here when a_blocked)."""
     M, K = A16.shape
     N = W16.shape[0]
-    table = tile_table(M, N, K, K, N)
+    table = tile_table(M, N, K, K, N, out_blocked=out_blocked)
     ntiles = table.shape[0]
     grid = min(grid, ntiles)
     outs = []
     for dma, ds, order in modes:
-        a_b = A16.view(np.uint8).reshape(-1).copy()
+        a_b = (to_blocked16(A16) if a_blocked else A16).view(np.uint8).reshape(-1).copy()
         w_b = W16.view(np.uint8).reshape(-1).copy()
         b_b = bias.astype(np.float32).view(np.uint8).reshape(-1).copy()
         o_b = np.full(M * N * 2, 0xFF, np.uint8)
@@ -730,7 +808,7 @@ def emulate(prog, A16, W16, bias, act, grid, modes=(("eager", "eager", "0123"),)
             wg.run()
             if verbose:
                 print(f"  wg {bid}: {wg.executed} instructions, max VMEM in flight {max(s_.max_vm for s_ in wg.waves)}")
-        outs.append(o_b.view(np.float16).reshape(M, N).copy())
+        outs.append(from_blocked16(o_b.view(np.float16), M, N) if out_blocked else o_b.view(np.float16).reshape(M, N).copy())
     return outs
 
 
@@ -774,6 +852,14 @@ VARIANTS = {       # probe builds: tools/probes/gemm_probe variants 71..76 (abla
 }
 
 
+PRODUCT_BODIES = {      # gemm_z192.hip includes gemm_z192_body_<name>.inc
+    "act0": dict(act=0),                              # qkv, proj (row-major in, row-major out)
+    "act1": dict(act=1),                              # GELU, row-major out (op-level use)
+    "act1_ob": dict(act=1, out_blocked=True),         # fc1 of the model: GELU, hidden activation written in the blocked-16 layout
+    "act0_ab": dict(act=0, a_blocked=True),           # fc2 of the model: reads the blocked-16 hidden activation
+}
+
+
 def variant_gen(k, act):
     kw = VARIANTS[k]
     sched = kw.get("sched_act1", kw["sched"]) if act == 1 else kw["sched"]
@@ -791,16 +877,15 @@ def main():
                 write_inc(os.path.join(sys.argv[2], f"z192_var{k}_act{act}.inc"), prog)
         return
     write_meta(os.path.join(root, "sam_road_amd", "csrc", "gemm_z192_meta.inc"))
-    for act in (0, 1):
-        g = ZGen(act=act, deferred=True)
-        prog = g.kernel()
+    for name, kw in PRODUCT_BODIES.items():
+        prog = ZGen(deferred=True, **kw).kernel()
         hz = check_hazards(prog)
         for h in hz[:20]:
             print("HAZARD:", h)
         assert not hz, f"{len(hz)} hazards"
-        path = os.path.join(root, "sam_road_amd", "csrc", f"gemm_z192_body_act{act}.inc")
+        path = os.path.join(root, "sam_road_amd", "csrc", f"gemm_z192_body_{name}.inc")
         write_inc(path, prog)
-        print(f"act {act}: {prog.n_real()} instructions -> {path}")
+        print(f"{name}: {prog.n_real()} instructions -> {path}")
 
 
 if __name__ == "__main__":

@@ -45,6 +45,22 @@ __global__ void spoil_kernel(const float4* a, float4* b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { float4 v = a[i]; v.x += 1.f; b[i] = v; }
 }
 
+// blocked-16 layout helpers (GemmParams::a_blocked16 / out_blocked16): variants 77 (output blocked) and 78 (A operand blocked)
+__global__ void to_blocked16(const f16* rm, f16* blk, int M, int N) {
+    const size_t n = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        blk[((size_t)(m / 32) * (N / 16) + c / 16) * 512 + ((c % 16) / 8) * 256 + (m % 32) * 8 + (c % 8)] = rm[i];
+    }
+}
+__global__ void from_blocked16(const f16* blk, f16* rm, int M, int N) {
+    const size_t n = (size_t)M * N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        rm[i] = blk[((size_t)(m / 32) * (N / 16) + c / 16) * 512 + ((c % 16) / 8) * 256 + (m % 32) * 8 + (c % 8)];
+    }
+}
+
 struct Shape { const char* name; int M, N, K, act; bool resid, f16out; };
 
 int main(int argc, char** argv) {
@@ -83,6 +99,9 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(db, hb.data(), s.N * 4, hipMemcpyHostToDevice));
         naive_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(dA, dW, db, dR, s.M, s.N, s.K, s.act, ref, LDA, LDW);
         CK(hipDeviceSynchronize());
+        f16 *dA_blk = nullptr, *o16_rm = nullptr;
+        if (LDA == s.K) { CK(hipMalloc(&dA_blk, nA * 2)); to_blocked16<<<2048, 256>>>(dA, dA_blk, s.M, s.K); }
+        CK(hipMalloc(&o16_rm, nO * 2));
         float* ws = nullptr;                                   // split-K workspace: 4 slices of f32 partials
         CK(hipMalloc(&ws, nO * 4 * 4));
         auto make = [&](int variant) {
@@ -94,6 +113,8 @@ int main(int argc, char** argv) {
             // variant 0 = what the library would do: split-K where its heuristic asks for it; 31 = 128x160 tiles with split-K 4
             if (variant == 0) { GemmParams t = g; t.variant = 0; const int sk = gemm_splitk_factor(t); if (sk > 1) { g.splitk = sk; g.split_ws = ws; } }
             if (variant == 31) { g.splitk = 4; g.split_ws = ws; }
+            if (variant == 77) { g.variant = 70; g.out_blocked16 = 1; }
+            if (variant == 78) { g.variant = 70; g.a_blocked16 = 1; g.A = dA_blk; }
             return g;
         };
         std::vector<std::vector<float>> times(variants.size());
@@ -103,7 +124,9 @@ int main(int argc, char** argv) {
             const GemmParams g = make(variants[vi]);
             const int rc = launch_gemm(g, 0);
             CK(hipDeviceSynchronize());
-            diff_kernel<<<1024, 256>>>(ref, s.f16out ? nullptr : o32, s.f16out ? o16 : nullptr, nO, dmax, dmax + 1);
+            const f16* o16_cmp = o16;
+            if (variants[vi] == 77) { from_blocked16<<<2048, 256>>>(o16, o16_rm, s.M, s.N); o16_cmp = o16_rm; }
+            diff_kernel<<<1024, 256>>>(ref, s.f16out ? nullptr : o32, s.f16out ? o16_cmp : nullptr, nO, dmax, dmax + 1);
             float h[2]; CK(hipMemcpy(h, dmax, 8, hipMemcpyDeviceToHost));
             printf("  check %-5s variant %3d rc=%d  max|diff|=%.3e  (max|ref|=%.2f)\n", s.name, variants[vi], rc, h[0], h[1]);
             if (variants[vi] == 53 || variants[vi] == 55) {

@@ -464,6 +464,31 @@ class Prog:
             return self._u((self._f(x).astype(np.float64) * self._f(y).astype(np.float64) + np.float64(np.float32(k))).astype(np.float32))
         self.add(f"v_fmaak_f32 {d}, {a}, {b}, {kk}", lambda st: self._vwrite(st, d, fn(self._vsrc(st, a), self._vsrc(st, b))), "valu", [a, b], [d])
 
+    def v_pk_fma_f32(self, d, a, b, c, bcast=(False, False, False), neg_a=False):
+        """Packed 2 x f32: d.lo = a.lo*b.lo + c.lo, d.hi = a.hi*b.hi + c.hi on 64-bit register pairs.  bcast[i]: source i feeds its LOW
+        dword to both halves (op_sel_hi = 0: a constant kept once); a float for c means an inline constant; neg_a negates a (both halves)."""
+        assert d.n == 2 and a.n == 2 and (isinstance(b, float) or b.n == 2)
+
+        def half(st, o, h, bc):
+            if isinstance(o, float):
+                return np.full(64, np.float32(o), np.float32).astype(np.float64)
+            idx = o.idx + (0 if bc else h)
+            if o.file == "s":
+                return np.full(64, np.uint32(st.s[idx]), np.uint32).view(np.float32).astype(np.float64)
+            return (st.v if o.file == "v" else st.a)[idx].view(np.float32).astype(np.float64)
+
+        def emu(st):
+            res = []
+            for h in range(2):
+                x = half(st, a, h, bcast[0]) * (-1.0 if neg_a else 1.0)
+                res.append((x * half(st, b, h, bcast[1]) + half(st, c, h, bcast[2])).astype(np.float32).view(np.uint32))
+            st.v[d.idx], st.v[d.idx + 1] = res[0], res[1]
+        osh = ",".join("0" if bc else "1" for bc in bcast)
+        txt = f"v_pk_fma_f32 {d}, {a}, {b}, {Lit(c) if isinstance(c, float) else c} op_sel_hi:[{osh}]"
+        if neg_a:
+            txt += " neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        self.add(txt, emu, "valu", [o for o in (a, b, c) if isinstance(o, Reg)], [d])
+
     def v_exp_f32(self, d, a):
         with np.errstate(over="ignore", under="ignore"):
             self._v_op("v_exp_f32", lambda x: self._u(np.exp2(self._f(x).astype(np.float64)).astype(np.float32)), d, [a], kind="trans")

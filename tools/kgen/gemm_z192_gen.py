@@ -49,9 +49,11 @@ TID, LANE, VW, VX = V(4), V(5), V(54), V(55)   # v4..v7 become a bias quad once 
 WF = V(8, 4)                              # W fragment LDS address per k-step
 XF = V(12, 12)                            # X fragment LDS address per (slot, k-step)
 VB, VBD, VC0, VBL = V(25), V(26), V(27), V(28)
+VC0P = V(62, 2)                            # packed-f32 GELU: c0 in the low dword of an even pair
 BQ = [V(30, 4), V(34, 4), V(50, 4), V(4, 4)]   # the 16 bias values of a W block (4 column groups); tuples are 64-bit aligned on gfx90a+
 GT = V(38, 12)                            # GELU temporaries: 4 elements in flight x (r, e, m)
 GC = [S(70), S(71), S(72), S(73)]         # GELU coefficients c1..c4 in the SGPRs the buffer sizes came in (c0 in VC0, c5 = 1.0 inline)
+GCP = [S(70, 2), S(72, 2), S(64, 2), S(36, 2)]   # packed-f32 GELU (sched gelu_pk): c1..c4 as the LOW dword of an even SGPR pair (the pairs are dead after the prologue: sizes, row pitches, kernarg pointer)
 TMP = GT                                  # prologue scratch (the GELU temporaries are idle then)
 VS = V(29)                                # staging write address: row (lane & 31), 16-byte half (lane >> 5)
 VR = [V(57), V(58), V(59)]                # staging read-back address per 1 KiB
@@ -221,8 +223,12 @@ class ZGen:
                 p.v_add_u32(VGO[r], T3, idx)
         p.s_lshl_b32(LDC16, LDC, 5)
         p.s_sub_u32(LDC16, LDC16, 5120 if self.out_blocked else 96)     # store offset step between row blocks: 32 rows on, 5 KiB / 96 B back
-        for k in range(4):
-            p.s_mov_b32(GC[k], float(GELU_C[k + 1]))
+        if self.sched.get("gelu_pk"):
+            for k in range(4):
+                p.s_mov_b32(GCP[k][0], float(GELU_C[k + 1]))
+        else:
+            for k in range(4):
+                p.s_mov_b32(GC[k], float(GELU_C[k + 1]))
         p.s_and_b32(T0, WAVE, 1)                          # wn again (T0 was reused)
         # bias: LDS read address (wn*96 + 4 fhalf) floats, DMA source offset wave*192 + lane*16
         p.s_mul_i32(T2, T0, 384)
@@ -233,6 +239,7 @@ class ZGen:
         p.v_lshlrev_b32(t3, 4, LANE)
         p.v_add_u32(VBD, T2, t3)
         p.v_mov_b32(VC0, float(GELU_C[0]))
+        p.v_mov_b32(VC0P[0], float(GELU_C[0]))
         # tiles of this workgroup: idx = bid, bid + grid, ...; my_tiles = ceil((ntiles - bid) / grid)   (bid < ntiles)
         p.s_sub_u32(T0, NTILES, BID)
         p.s_add_u32(T0, T0, GRID)
@@ -400,7 +407,49 @@ class ZGen:
                         for e in es:
                             p.v_add_f32(B[4 * q + e], B[4 * q + e], BQ[q][e])
                     atom_halves(addb)
-                if self.act == 1:
+                if self.act == 1 and self.sched.get("gelu_pk"):
+                    # packed-f32 form: 12 VALU per element PAIR (2 v_and, 5 v_pk_fma, 2 v_exp, 2 v_max, 1 v_pk_fma) instead of 16
+                    for g0 in range(0, 16, 4):
+                        prs = [(B.sub(g0 + 2 * k, 2), GT.sub(6 * k, 2), GT.sub(6 * k + 2, 2), GT.sub(6 * k + 4, 2)) for k in range(2)]
+
+                        def pa(prs=prs):
+                            for x, a_, r_, m_ in prs:
+                                p.v_and_b32(a_[0], 0x7FFFFFFF, x[0])
+                                p.v_and_b32(a_[1], 0x7FFFFFFF, x[1])
+                        atom(4, "valu", pa)
+
+                        def p1(prs=prs):
+                            for x, a_, r_, m_ in prs:
+                                p.v_pk_fma_f32(r_, a_, VC0P, GCP[0], bcast=(False, True, True))
+                        atom(2, "valu", p1)
+                        for c in (1, 2, 3):
+                            def p2(prs=prs, c=c):
+                                for x, a_, r_, m_ in prs:
+                                    p.v_pk_fma_f32(r_, r_, a_, GCP[c], bcast=(False, False, True))
+                            atom(2, "valu", p2)
+
+                        def p5(prs=prs):
+                            for x, a_, r_, m_ in prs:
+                                p.v_pk_fma_f32(r_, r_, a_, 1.0, bcast=(False, False, True))
+                        atom(2, "valu", p5)
+
+                        def pe(prs=prs):
+                            for x, a_, r_, m_ in prs:
+                                p.v_exp_f32(r_[0], neg(r_[0]))
+                                p.v_exp_f32(r_[1], neg(r_[1]))
+                        atom(4, "valu", pe)
+
+                        def pm(prs=prs):
+                            for x, a_, r_, m_ in prs:
+                                p.v_max_f32(m_[0], 0, x[0])
+                                p.v_max_f32(m_[1], 0, x[1])
+                        atom(4, "valu", pm)
+
+                        def po(prs=prs):
+                            for x, a_, r_, m_ in prs:
+                                p.v_pk_fma_f32(x, a_, r_, m_, neg_a=True)
+                        atom(2, "valu", po)
+                elif self.act == 1:
                     for g0 in range(0, 16, 4):
                         x = [B[g0 + e] for e in range(4)]
                         r_ = [GT[3 * e] for e in range(4)]
@@ -842,11 +891,11 @@ def write_inc(path, prog):
 
 
 VARIANTS = {       # probe builds: tools/probes/gemm_probe variants 71..76 (ablations give wrong results).  The sets measured in round 4
-    # (profiles/r04_z192_*.txt) were edited here between runs; this is the last one: what does a deferred epilogue cost, step by step?
+    # (profiles/r04_z192_*.txt) were edited here between runs; this is the last one.
     1: dict(deferred=True, sched=dict(no_epi=True)),                        # k-loops only
-    2: dict(deferred=True, sched=dict(burst_drain=True)),                   # accumulators drained in one burst at the tile switch
-    3: dict(deferred=True, sched=dict(no_stage=True)),                      # drain + bias / activation / pack, nothing leaves
-    4: dict(deferred=True, sched=dict(no_store=True)),                      # + LDS staging
+    2: dict(deferred=True, sched=dict(gelu_pk=True)),                       # GELU in packed f32 (12 VALU per element pair instead of 16)
+    3: dict(deferred=True, sched=dict(gelu_pk=True, gap_slots=8, epi_in_dma_gaps=True)),
+    4: dict(deferred=True, sched=dict(no_store=True)),                      # everything but the global stores
     5: dict(deferred=True, sched=dict(gelu_dummy=1)),                       # the product schedule with every GELU instruction a v_mov
     6: dict(deferred=False, sched=dict()),                                  # exposed epilogue after every tile
 }

@@ -12,6 +12,11 @@ LIB = os.path.join(HERE, "libsamroad_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "gemm_q192.hip", "gemm_z192.hip", "norm.hip", "patch.hip", "attention.hip", "attention_hdx.hip", "decoder.hip", "sam_decoder.hip", "topo.hip", "topo_fused.hip", "host_geom.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
+# The softmax row maxima are taken over MFMA results; without this flag every fmaxf operand gets a v_max x, x to quiet a
+# possible signalling NaN first (16 extra VALU instructions per 64 keys in a VALU-bound loop).  No NaN arises in these kernels
+# (-inf - finite and exp2(-inf) are fine); infinities ARE used, so no -ffinite-math-only.
+FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "attention_hdx.hip": ["-fno-honor-nans"]}
+
 
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
@@ -34,7 +39,7 @@ def source_id():
         with open(f, "rb") as fh:
             h.update(fh.read())
         h.update(b"\0")
-    h.update(" ".join(FLAGS + SOURCES).encode())
+    h.update(" ".join(FLAGS + SOURCES + [f"{k}:{' '.join(v)}" for k, v in sorted(FILE_FLAGS.items())]).encode())
     return h.hexdigest()[:16]
 
 
@@ -63,7 +68,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + [f'-DSRH_BUILD_ID_HEX="{sid}"', "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + [f'-DSRH_BUILD_ID_HEX="{sid}"', "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

@@ -7,11 +7,13 @@
 //
 // gfx950 design.  Everything is issued transposed so that one lane owns one query:
 //   S^T[key, q] = K[key,:] . Q[q,:]      A operand = K rows (LDS), B operand = Q rows (registers)
-//   O^T[d,   q] = V^T[d,key] . P^T[key,q] A operand = V^T rows (LDS), B operand = P (registers)
+//   O^T[d,   q] = V^T[d,key] . P^T[key,q] A operand = V^T fragments (row-major V rows in LDS, read transposed
+//                                          with ds_read_b64_tr_b16), B operand = P (registers)
 // with v_mfma_f32_32x32x16_f16.  In the C/D layout lane l holds query (l & 31) and 16 of the 32 keys
 // (rows (r&3) + 8(r>>2) + 4(l>>5)), so the softmax max/sum are lane-local plus ONE cross-half
-// exchange, the running rescale is lane-local, and the exponentiated tile is ALREADY the B fragment
-// of the P.V product if V^T is stored with the same key permutation — no P round trip through LDS.
+// exchange (v_permlane32_swap), the running rescale is lane-local, and the exponentiated tile is ALREADY the B
+// fragment of the P.V product if the V^T fragment gathers its keys in the same order — no P round trip through LDS.
+// (attention_hdx.hip, head dim 80, still stages a transposed, key-permuted V^T image with v_perm.)
 // The rel-pos bias enters as the MFMA accumulator's initial value (f32, pre-divided by scale).
 // Key tiles hold 32 MFMA rows = whole window rows (2 rows of 14 -> 28 valid keys, 2 rows of 16, or
 // 1 row of 32), so the per-lane rel_w values repeat for every tile and rel_h is 1-2 scalars per tile.
@@ -34,12 +36,6 @@ template <int WIN> __device__ __forceinline__ void tile_rc(int i, int& r, int& c
     if (WIN == 32) { r = 0; c = i; }
     else if (WIN == 16) { r = i >> 4; c = i & 15; }
     else { r = i >= 14; c = i - 14 * r; }
-}
-
-// V^T slot of local key i: the key permutation that makes exp(S^T) registers the P^T B-fragment
-__device__ __forceinline__ int vt_slot(int i) {
-    const int half = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
-    return ((reg >> 3) * 2 + half) * 8 + (reg & 7);
 }
 
 struct QState {
@@ -115,21 +111,13 @@ __device__ __forceinline__ void tile_exp(const f32x16& s, float rh0, float rh1, 
     }
 }
 
-__device__ __forceinline__ void read_vfrag(f16x8 (&vf)[2][2], const char* vt_lds, int lane) {
-    const int half = lane >> 5, row = lane & 31;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            const int d = dt * 32 + row;
-            const int c = (sx * 2 + half) ^ ((d >> 2) & 3);
-            vf[dt][sx] = *reinterpret_cast<const f16x8*>(vt_lds + d * 64 + c * 16);
-        }
-}
-
 // running max / rescale shared by the one- and two-tile forms: returns the new max (raw units)
+// cross-half exchanges use v_permlane32_swap_b32 (one VALU instruction) instead of a ds_bpermute round trip through LDS
 __device__ __forceinline__ float update_max(QState& st, float mloc, float c_exp) {
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    {   // max over both halves: after the swap r[0] = {lo, lo}, r[1] = {hi, hi}
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+        mloc = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
     const float m_new = fmaxf(st.m, mloc);
     // rescale the running state only when some lane's max moved (wave-uniform branch; after the first
     // few key tiles the max is usually stable and the 32 accumulator multiplies are skipped)
@@ -143,63 +131,6 @@ __device__ __forceinline__ float update_max(QState& st, float mloc, float c_exp)
         st.m = m_new;
     }
     return m_new;
-}
-
-template <int WIN>
-__device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], const char* vt_lds,
-                                          float rh0, float rh1, float c_exp, int lane) {
-    const int half = lane >> 5;
-    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
-    f16x8 vf[2][2];
-    read_vfrag(vf, vt_lds, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    const float m_new = update_max(st, tile_max<WIN>(s, rh0, rh1, half), c_exp);
-    f32x2 sum2 = {0.f, 0.f};
-    f16x8 pb[2];
-    tile_exp<WIN>(s, rh0, rh1, m_new, c_exp, half, pb, sum2);
-    st.l += sum2[0] + sum2[1];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) st.o[dt] = mfma32(vf[dt][sx], pb[sx], st.o[dt]);
-}
-
-// TWO 32-row key tiles at once (round 3).  A wave's key loop was bound by the dependency CHAIN of one tile, not by any
-// pipe: four dependent S^T MFMAs (64 clk of latency each at 32 clk of issue), the 16-deep row-max tree, the cross-half
-// exchange (an LDS round trip), the exps, then two 2-deep P.V chains — about 1000 clk end to end with one more wave per SIMD to
-// fill the gaps (2470 clk per tile and wave measured, MFMA busy 21 %, VALU ~50 %).  With two tiles in flight the two S^T chains
-// interleave (the matrix pipe is paced instead of waiting on its own result), the two max trees are independent, there is ONE
-// exchange / rescale decision / row-sum update per 64 keys, twice as many independent exps per dependency level, and the
-// eight P.V MFMAs alternate between the two O^T accumulators.  Same arithmetic as two attn_tile calls except that both tiles
-// are exponentiated against the max over all 64 keys.
-template <int WIN>
-__device__ __forceinline__ void attn_tile2(QState& st, const f16x8 (&kfa)[4], const f16x8 (&kfb)[4], const char* vta, const char* vtb,
-                                           float rh0a, float rh1a, float rh0b, float rh1b, float c_exp, int lane) {
-    const int half = lane >> 5;
-    f32x16 sa = mfma32(kfa[0], st.q[0], st.relw);
-    f32x16 sb = mfma32(kfb[0], st.q[0], st.relw);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) { sa = mfma32(kfa[ks], st.q[ks], sa); sb = mfma32(kfb[ks], st.q[ks], sb); }
-    f16x8 vfa[2][2], vfb[2][2];
-    read_vfrag(vfa, vta, lane);
-    read_vfrag(vfb, vtb, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    const float m_new = update_max(st, fmaxf(tile_max<WIN>(sa, rh0a, rh1a, half), tile_max<WIN>(sb, rh0b, rh1b, half)), c_exp);
-    f32x2 sum2 = {0.f, 0.f};
-    f16x8 pa[2], pb[2];
-    tile_exp<WIN>(sa, rh0a, rh1a, m_new, c_exp, half, pa, sum2);
-    tile_exp<WIN>(sb, rh0b, rh1b, m_new, c_exp, half, pb, sum2);
-    st.l += sum2[0] + sum2[1];
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) st.o[dt] = mfma32(vfa[dt][sx], pa[sx], st.o[dt]);
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) st.o[dt] = mfma32(vfb[dt][sx], pb[sx], st.o[dt]);
 }
 
 template <int WIN>
@@ -266,7 +197,12 @@ __device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, in
 __device__ __forceinline__ void store_query(const QState& st, const AttnParams& p, size_t tok, int head,
                                             int lane, bool valid) {
     const int half = lane >> 5;
-    const float inv = 1.0f / (st.l + __shfl_xor(st.l, 32, 64));
+    float lsum;
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(st.l), __float_as_uint(st.l), false, false);
+        lsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const float inv = 1.0f / lsum;
     if (!valid) return;
     f16* o = p.out + tok * p.ldo + head * HD;
 #pragma unroll
@@ -280,49 +216,179 @@ __device__ __forceinline__ void store_query(const QState& st, const AttnParams& 
         }
 }
 
-// Stage a 4-key x 8-dim block of V into the transposed, key-permuted V^T tile.
-__device__ __forceinline__ uint32_t u4_word(const uint4& v, int i) {
-    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
-}
-__device__ __forceinline__ uint32_t u4_half(const uint4& v, int e) {   // e-th fp16 of the 8
-    const uint32_t w = u4_word(v, e >> 1);
-    return (e & 1) ? (w >> 16) : (w & 0xffffu);
-}
-__device__ __forceinline__ void vt_write(char* vt, int kq, int dc, const uint4& v0, const uint4& v1,
-                                         const uint4& v2, const uint4& v3) {
-    const int slot = vt_slot(kq * 4);
-    const int c = slot >> 3, eo = slot & 7;   // eo is 0 or 4
-    // 4 keys x 8 dims -> 8 dims x 4 keys: every output word pairs the same fp16 of two keys = ONE v_perm_b32
-    // (byte select 0x05040100: low halves, 0x07060302: high halves) instead of shift / and / or chains
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int d = dc * 8 + e;
-        const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
-        uint2 w;
-        w.x = __builtin_amdgcn_perm(u4_word(v1, e >> 1), u4_word(v0, e >> 1), sel);
-        w.y = __builtin_amdgcn_perm(u4_word(v3, e >> 1), u4_word(v2, e >> 1), sel);
-        *reinterpret_cast<uint2*>(vt + d * 64 + ((c ^ ((d >> 2) & 3)) * 16) + eo * 2) = w;
-    }
+// ---------------------------------------------------------------------------------------------
+// Windowed attention: one workgroup per (image, head, window); the whole window's K and V (196 keys incl. pad keys) are
+// staged once, then each wave walks its 32-query tiles.
+//  * K rows and ROW-MAJOR V rows go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 key rows per wave
+//    instruction): no staging registers, no ds_write, no v_perm transposition.  The DMA destination is lane-linear, so the
+//    swizzles live on the SOURCE side: LDS slot (row i, 16-B position c') receives chunk c' ^ ((i >> 1) & 7) of the K row
+//    (read_kfrag's swz8) and chunk c' ^ 4 * ((i >> 1) & 1) of the V row.
+//  * The P.V A fragments (V^T[d, key]) are read from the row-major V image with ds_read_b64_tr_b16: a 16-lane group hands
+//    in the addresses of a [4 keys][16 dims] block (lane i: key i / 4, dims 4 (i % 4) ..), lane c of the group receives
+//    dims c of the 4 keys.  Two reads give the 8 keys of a fragment; which 4-key groups is dictated by the S^T C layout
+//    (keys 16 sx + 4 half + 0..3 and the same + 8), so that exp(S^T) stays the B fragment as before.  The V swizzle makes
+//    the 32-lane phase of a read (4 keys x 64 B) touch each of the 64 banks once.
+//  * MFMA rows 28..31 of a tile are not keys: their K / V slots get a copy of key 0 of the tile (finite values, P = 0).
+//  * Windows with one or two query tiles (the edge / corner windows: 5 of the 9 windows of a 512-px tile, 196 keys each
+//    because pad tokens are real keys) used to park two or three of the four waves for the whole key loop.  They now split
+//    the KEY tiles over the waves ([0,4) | [4,7) for two query tiles, [0,2) | [2,4) | [4,6) | [6,7) for one) and merge the
+//    partial (max, sum, O) through LDS with the usual online-softmax rescale.
+// ---------------------------------------------------------------------------------------------
+typedef __fp16 h4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+constexpr int WIN_LDS_K = 7 * 4096, WIN_LDS_V = 7 * 4096, WIN_LDS_TBL = 2 * 4096, WIN_LDS_RH = 4 * 32 * 17 * 4;
+constexpr int WIN_LDS = WIN_LDS_K + WIN_LDS_V + WIN_LDS_TBL + WIN_LDS_RH;     // 74 240 B: two workgroups per CU
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Windowed attention: one workgroup per (image, head, window); the whole window's K and V^T
-// (196 keys incl. pad keys) are staged once, then each wave walks its 32-query tiles.
-// (Round 2 tried a PERSISTENT 8-wave form — one workgroup per CU, one wave per query tile, the next item's K / V / q prefetched
-// into registers during the key loop: correct but 48 % SLOWER, 85 vs 57 us per launch, profiles/r02_attn_window_p8.txt.  A
-// query tile's key loop costs ~6.5 us of VALU-issue-bound work, so an edge / corner window (2 / 1 tiles) parks 6 / 7 of the 8
-// waves for a whole tile time; with two independent 4-wave workgroups per CU the idle waves of one leave their SIMD's issue
-// slots to the other, and one workgroup's prologue overlaps the other's key loop.  History: git log.)
-// ---------------------------------------------------------------------------------------------
-constexpr int WIN_LDS_K = 7 * 4096, WIN_LDS_VT = 7 * 4096, WIN_LDS_RH = 4 * 32 * 17 * 4;
-constexpr int WIN_LDS = WIN_LDS_K + WIN_LDS_VT + WIN_LDS_RH;
+__device__ __forceinline__ f16x8 tr_read8(const char* a) {
+    struct Pair { h4v lo, hi; } pr;
+    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4v*)a);
+    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4v*)(a + 1024));   // keys + 8
+    return __builtin_bit_cast(f16x8, pr);
+}
+
+// lane bases of the transposed V reads: d tile 0 / d tile 1 (the swizzle XORs bit 2 of the chunk, so dt is not additive)
+__device__ __forceinline__ void vtr_bases(int lane, int& vb0, int& vb1) {
+    const int i = lane & 15, g = (lane >> 4) & 1, half = lane >> 5;
+    const int sw = (i >> 3) & 1;                                   // ((key >> 1) & 1) with key = 4 * group + i / 4
+    vb0 = (4 * half + (i >> 2)) * 128 + (((g * 2 + ((i >> 1) & 1)) ^ (4 * sw)) * 16) + (i & 1) * 8;
+    vb1 = vb0 ^ 64;
+}
+
+__device__ __forceinline__ void read_vfrag(f16x8 (&vf)[2][2], const char* v_tile, int vb0, int vb1) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) vf[dt][sx] = tr_read8(v_tile + (dt ? vb1 : vb0) + sx * 2048);
+}
+
+template <int WIN>
+__device__ __forceinline__ void attn_tile(QState& st, const f16x8 (&kf)[4], const char* v_tile, int vb0, int vb1,
+                                             float rh0, float rh1, float c_exp, int lane) {
+    const int half = lane >> 5;
+    f32x16 s = mfma32(kf[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) s = mfma32(kf[ks], st.q[ks], s);
+    f16x8 vf[2][2];
+    read_vfrag(vf, v_tile, vb0, vb1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m_new = update_max(st, tile_max<WIN>(s, rh0, rh1, half), c_exp);
+    f32x2 sum2 = {0.f, 0.f};
+    f16x8 pb[2];
+    tile_exp<WIN>(s, rh0, rh1, m_new, c_exp, half, pb, sum2);
+    st.l += sum2[0] + sum2[1];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) st.o[dt] = mfma32(vf[dt][sx], pb[sx], st.o[dt]);
+}
+
+// TWO 32-row key tiles at once (round 3).  A wave's key loop was bound by the dependency CHAIN of one tile, not by any
+// pipe: four dependent S^T MFMAs (64 clk of latency each at 32 clk of issue), the 16-deep row-max tree, the cross-half
+// exchange (an LDS round trip), the exps, then two 2-deep P.V chains — about 1000 clk end to end with one more wave per SIMD to
+// fill the gaps (2470 clk per tile and wave measured, MFMA busy 21 %, VALU ~50 %).  With two tiles in flight the two S^T chains
+// interleave (the matrix pipe is paced instead of waiting on its own result), the two max trees are independent, there is ONE
+// exchange / rescale decision / row-sum update per 64 keys, twice as many independent exps per dependency level, and the
+// eight P.V MFMAs alternate between the two O^T accumulators.  Same arithmetic as two attn_tile calls except that both tiles
+// are exponentiated against the max over all 64 keys.
+template <int WIN>
+__device__ __forceinline__ void attn_tile2(QState& st, const f16x8 (&kfa)[4], const f16x8 (&kfb)[4], const char* va, const char* vb,
+                                              int vb0, int vb1, float rh0a, float rh1a, float rh0b, float rh1b, float c_exp, int lane) {
+    const int half = lane >> 5;
+    f32x16 sa = mfma32(kfa[0], st.q[0], st.relw);
+    f32x16 sb = mfma32(kfb[0], st.q[0], st.relw);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) { sa = mfma32(kfa[ks], st.q[ks], sa); sb = mfma32(kfb[ks], st.q[ks], sb); }
+    f16x8 vfa[2][2], vfb[2][2];
+    read_vfrag(vfa, va, vb0, vb1);
+    read_vfrag(vfb, vb, vb0, vb1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float m_new = update_max(st, fmaxf(tile_max<WIN>(sa, rh0a, rh1a, half), tile_max<WIN>(sb, rh0b, rh1b, half)), c_exp);
+    f32x2 sum2 = {0.f, 0.f};
+    f16x8 pa[2], pb[2];
+    tile_exp<WIN>(sa, rh0a, rh1a, m_new, c_exp, half, pa, sum2);
+    tile_exp<WIN>(sb, rh0b, rh1b, m_new, c_exp, half, pb, sum2);
+    st.l += sum2[0] + sum2[1];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) st.o[dt] = mfma32(vfa[dt][sx], pa[sx], st.o[dt]);
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) st.o[dt] = mfma32(vfb[dt][sx], pb[sx], st.o[dt]);
+}
+
+// key tiles [t0, t1) of a 14 x 14 window for one query tile: pairs, then a single tile if the count is odd
+__device__ __forceinline__ void window_keys(QState& st, const char* k_lds, const char* v_lds, const float* rhq, int t0, int t1,
+                                            int vb0, int vb1, float c_exp, int lane) {
+    constexpr int WIN = 14;
+    f16x8 kfA[4], kfB[4];
+    int t = t0;
+    read_kfrag(kfA, k_lds + t * 4096, lane);
+    if (t + 1 < t1) read_kfrag(kfB, k_lds + (t + 1) * 4096, lane);
+#pragma unroll 1
+    for (; t + 1 < t1; t += 2) {
+        const float rh0a = rhq[2 * t], rh1a = rhq[2 * t + 1], rh0b = rhq[2 * t + 2], rh1b = rhq[2 * t + 3];
+        attn_tile2<WIN>(st, kfA, kfB, v_lds + t * 4096, v_lds + (t + 1) * 4096, vb0, vb1, rh0a, rh1a, rh0b, rh1b, c_exp, lane);
+        if (t + 2 < t1) read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
+        if (t + 3 < t1) read_kfrag(kfB, k_lds + (t + 3) * 4096, lane);
+    }
+    if (t < t1) attn_tile<WIN>(st, kfA, v_lds + t * 4096, vb0, vb1, rhq[2 * t], rhq[2 * t + 1], c_exp, lane);
+}
+
+// fused decomposed rel-pos bias of one 32-query tile of a 14 x 14 window (see fused_relpos): w table -> st.relw, h table -> rh
+__device__ __forceinline__ void window_relpos(QState& st, const char* tbl_lds, int rx, int ry, float* rh, float inv_scale, int lane) {
+    constexpr int WIN = 14;
+    f16x8 tfrag[2][4];                                 // A operand rows j = lane & 31 of the 27-row tables, staged in LDS in the K-tile format
+    read_kfrag(tfrag[0], tbl_lds, lane);
+    read_kfrag(tfrag[1], tbl_lds + 4096, lane);
+    const int half = lane >> 5;
+    float* row = rh + (lane & 31) * 17;                // rel[q][1 + k], k = 0..13; slots 0 and 15 collect the table rows that map outside the window
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qc = pass == 0 ? rx : ry;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = mfma32(tfrag[pass][ks], st.q[ks], acc);
+        // P^T[j, q] -> rel[q][k = qc - j + 13]: one subtract, one clamp (v_med3) and an unconditional write per element instead of
+        // three compares and an exec-masked write; table rows 27..31 (copies of row 26) land on k < 0, i.e. in the dump slot
+        const int kb = qc + WIN - 1 - 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kb - ((r & 3) + 8 * (r >> 2));
+            row[min(max(k, -1), WIN) + 1] = acc[r] * inv_scale;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (pass == 0) {
+            // the lane's 16 keys of a tile are window columns {0..3, 8..11, 2..5, 10..13} (half 0) / {4..7, 12, 13, 0, 1, 6..9, none} (half 1):
+            // lane base + immediate for every read
+            const float* rd = row + 1 + 4 * half;
+            const float* rd67 = row + 1 + (half ? 0 : 10);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                constexpr int c0[16] = {0, 1, 2, 3, 8, 9, 10, 11, 2, 3, 4, 5, 10, 11, 12, 13};
+                float v = (r == 6 || r == 7) ? rd67[r - 6] : rd[c0[r]];
+                if (r >= 12) v = half ? 0.f : v;               // MFMA rows 28..31 are not keys
+                st.relw[r] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
     constexpr int WIN = 14;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
-    char* vt_lds = smem + WIN_LDS_K;
-    float* rh_lds = reinterpret_cast<float*>(smem + WIN_LDS_K + WIN_LDS_VT);
+    char* v_lds = smem + WIN_LDS_K;
+    char* tbl_lds = smem + WIN_LDS_K + WIN_LDS_V;                       // rel-pos tables w | h as two more "K tiles"
+    float* rh_lds = reinterpret_cast<float*>(smem + WIN_LDS_K + WIN_LDS_V + WIN_LDS_TBL);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S, nw = (S + WIN - 1) / WIN, D = p.heads * HD;
     int u = blockIdx.x;
@@ -334,162 +400,138 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
     const int nreal = nry * nrx;
     const int ntq = (nreal + 31) / 32;
     const int half = lane >> 5;
-    const bool fused = p.ablate != 3;
+    if (p.ablate == 7) return;                                           // launch floor (tuning builds only reach this)
+    // work split (workgroup-uniform): ntq <= 2 -> the waves share query tiles and split the key tiles
+    const bool split = ntq <= 2 && p.ablate != 5;
+    const int nsplit = split ? 4 / ntq : 1;
+    const int part = split ? wave / ntq : 0;
+    const int jt0 = split ? wave % ntq : wave;
+    int t0 = 0, t1 = 7;
+    if (nsplit == 2) { t0 = part ? 4 : 0; t1 = part ? 7 : 4; }
+    else if (nsplit == 4) { t0 = 2 * part; t1 = min(2 * part + 2, 7); }
 
-    // ---- Every global load of the workgroup is issued up front, so their latencies overlap ONCE: the K / V rows to
-    // stage, the query fragments of this wave's (up to two) query tiles and the rel-pos table fragments.  (Measured
-    // before: the key loop was 23 % of the kernel; staging, per-tile query / table loads and their exposed latencies
-    // were the rest.)
-    // K items: thread (chunk c, local row i) of every tile t = 0..6
-    const int s_c = tid & 7, s_i = (tid >> 3) & 31;
-    uint4 kreg[7];
+    // ---- Loads: the rel-pos tables (LDS-DMA), the query fragments, then the K / V rows (LDS-DMA, wave w fills MFMA rows
+    // 8w .. 8w+7 of every tile)
+    const int i = wave * 8 + (lane >> 3), cpos = lane & 7;
+    const int ck = cpos ^ ((i >> 1) & 7), cv = cpos ^ (((i >> 1) & 1) * 4);
     {
-        int rr, cc;
-        tile_rc<WIN>(s_i < 28 ? s_i : 0, rr, cc);
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const int y = wy * WIN + t * 2 + rr, x = wx * WIN + cc;
-            const f16* src = (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + D + head * HD
-                                              : p.bias_qkv + D + head * HD;
-            kreg[t] = *reinterpret_cast<const uint4*>(src + s_c * 8);
-        }
+        const int jrow = min(i, 2 * WIN - 2);                            // table rows 27..31 do not exist: their products are never used
+        dma16(p.table_w + (size_t)jrow * HD + ck * 8, tbl_lds + wave * 1024);
+        dma16(p.table_h + (size_t)jrow * HD + ck * 8, tbl_lds + 4096 + wave * 1024);
     }
-    // V items: thread (d chunk dc, key quad kq) of tiles t = wave and wave + 4
-    const int s_dc = tid & 7, s_kq = (tid >> 3) & 7;
-    uint4 vreg[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int t = wave + 4 * j;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = s_kq * 4 + e;
-            int rr, cc;
-            tile_rc<WIN>(i < 28 ? i : 0, rr, cc);
-            const int y = wy * WIN + min(t, 6) * 2 + rr, x = wx * WIN + cc;
-            const f16* src = (y < S && x < S) ? p.qkv + (((size_t)b * S + y) * S + x) * p.ld + 2 * D + head * HD
-                                              : p.bias_qkv + 2 * D + head * HD;
-            vreg[j][e] = *reinterpret_cast<const uint4*>(src + s_dc * 8);
-        }
-    }
-    // query fragments of this wave's tiles jt = wave, wave + 4
     f16x8 qpre[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int qi = min((wave + 4 * j) * 32 + (lane & 31), nreal - 1);
+        const int jt = j == 0 ? jt0 : wave + 4;
+        const int qi = min(jt * 32 + (lane & 31), nreal - 1);
         const size_t tokq = ((size_t)b * S + wy * WIN + qi / nrx) * S + wx * WIN + qi % nrx;
         const f16* q = p.qkv + tokq * p.ld + head * HD;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qpre[j][ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
     }
-    // rel-pos table fragments (A operand rows j = lane & 31 of the 27-row tables)
-    f16x8 tfrag[2][4];
-    if (fused) {
-        const int j = min(lane & 31, 2 * WIN - 2);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            tfrag[0][ks] = *reinterpret_cast<const f16x8*>(p.table_w + (size_t)j * HD + (ks * 2 + half) * 8);
-            tfrag[1][ks] = *reinterpret_cast<const f16x8*>(p.table_h + (size_t)j * HD + (ks * 2 + half) * 8);
-        }
-    }
-
-    // ---- stage K rows and the transposed, key-permuted V^T tiles
     if (p.ablate != 2) {
+        const int ii = i < 28 ? i : 0;
+        const int rr = ii >= 14, cc = ii - 14 * rr;
+        const int x = wx * WIN + cc;
+        const f16* padk = p.bias_qkv + D + head * HD + ck * 8;
+        const f16* padv = p.bias_qkv + 2 * D + head * HD + cv * 8;
+        const f16* row0 = p.qkv + (((size_t)b * S + wy * WIN + rr) * S + x) * p.ld + head * HD;
+        const size_t tstride = (size_t)2 * S * p.ld;
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
-            const uint4 v = s_i < 28 ? kreg[t] : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(k_lds + t * 4096 + s_i * 128 + swz8(s_i, s_c) * 16) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int t = wave + 4 * j;
-            if (t < 7) {
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                const int i0 = s_kq * 4;
-                vt_write(vt_lds + t * 4096, s_kq, s_dc, i0 < 28 ? vreg[j][0] : z, i0 + 1 < 28 ? vreg[j][1] : z,
-                         i0 + 2 < 28 ? vreg[j][2] : z, i0 + 3 < 28 ? vreg[j][3] : z);
-            }
+            const bool real = (wy * WIN + 2 * t + rr) < S && x < S;
+            const f16* row = row0 + t * tstride;
+            dma16(real ? row + D + ck * 8 : padk, k_lds + t * 4096 + wave * 1024);
+            dma16(real ? row + 2 * D + cv * 8 : padv, v_lds + t * 4096 + wave * 1024);
         }
     }
+    // (Running the first query tile's rel-pos under the K / V loads — wait for the tables and q only, vmcnt(14) — is not expressible
+    // here: the compiler puts its own vmcnt(0) in front of every LDS read while any LDS-DMA is in flight.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA writes have landed; all waves' after the barrier
     __syncthreads();
 
     const float c_exp = p.scale * 1.4426950408889634f;
     const float inv_scale = 1.0f / p.scale;
     float* rh = rh_lds + wave * 32 * 17;
+    const float* rhq = rh + (lane & 31) * 17 + 1;
+    int vb0, vb1;
+    vtr_bases(lane, vb0, vb1);
+    QState st;
+    size_t tok = 0;
+    bool valid = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int jt = wave + 4 * j;
-        if (jt >= ntq) break;
-        const int qi_raw = jt * 32 + (lane & 31);
-        const bool valid = qi_raw < nreal;
-        const int qi = valid ? qi_raw : nreal - 1;
-        const int ry = qi / nrx, rx = qi % nrx;
-        const size_t tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
-        QState st;
+        const int jt = j == 0 ? jt0 : wave + 4;
+        const bool has = jt < ntq && !(j == 1 && split);
+        if (has) {
+            const int qi_raw = jt * 32 + (lane & 31);
+            valid = qi_raw < nreal;
+            const int qi = valid ? qi_raw : nreal - 1;
+            const int ry = qi / nrx, rx = qi % nrx;
+            tok = ((size_t)b * S + wy * WIN + ry) * S + wx * WIN + rx;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st.q[ks] = qpre[j][ks];
-        st.m = -INFINITY;
-        st.l = 0.f;
+            for (int ks = 0; ks < 4; ++ks) st.q[ks] = qpre[j][ks];
+            st.m = -INFINITY;
+            st.l = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
-        if (fused) {
-            // fused rel-pos bias (see fused_relpos): w table -> st.relw, then h table -> rh
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int qc = pass == 0 ? rx : ry;
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = mfma32(tfrag[pass][ks], st.q[ks], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int jrow = mfma32_row(r, lane);
-                    const int k = qc - jrow + WIN - 1;
-                    if (k >= 0 && k < WIN && jrow < 2 * WIN - 1) rh[(lane & 31) * 17 + k] = acc[r] * inv_scale;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (pass == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int rr, cc;
-                        tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
-                        st.relw[r] = (cc < WIN) ? rh[(lane & 31) * 17 + cc] : 0.f;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
+                for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
+            if (p.ablate != 3) window_relpos(st, tbl_lds, rx, ry, rh, inv_scale, lane);
         }
-        if (p.ablate != 1) {
-            // tiles 0..5 as three PAIRS (attn_tile2: two independent S^T chains / max trees in flight, one exchange and rescale
-            // decision per 56 keys), then tile 6.  The next pair's K fragments are read right behind the current pair's call: by then
-            // its S^T MFMAs have consumed the registers, and the reads' latency hides behind the pair's softmax
-            f16x8 kfA[4], kfB[4];
-            read_kfrag(kfA, k_lds, lane);
-            read_kfrag(kfB, k_lds + 4096, lane);
-            const float* rhq = rh + (lane & 31) * 17;
-#pragma unroll 1
-            for (int t = 0; t < 6; t += 2) {
-                const float rh0a = rhq[2 * t], rh1a = rhq[2 * t + 1], rh0b = rhq[2 * t + 2], rh1b = rhq[2 * t + 3];
-                attn_tile2<WIN>(st, kfA, kfB, vt_lds + t * 4096, vt_lds + (t + 1) * 4096, rh0a, rh1a, rh0b, rh1b, c_exp, lane);
-                read_kfrag(kfA, k_lds + (t + 2) * 4096, lane);
-                if (t < 4) read_kfrag(kfB, k_lds + (t + 3) * 4096, lane);
-            }
-            attn_tile<WIN>(st, kfA, vt_lds + 6 * 4096, rhq[12], rhq[13], c_exp, lane);
+        if (!has) continue;
+        if (p.ablate != 1) window_keys(st, k_lds, v_lds, rhq, t0, t1, vb0, vb1, c_exp, lane);
+#ifdef SRH_TUNING
+        if (p.ablate == 8)                               // key loop x 4: (time - normal) / 3 = the key loops alone
+            for (int rep = 0; rep < 3; ++rep) window_keys(st, k_lds, v_lds, rhq, t0, t1, vb0, vb1, c_exp, lane);
+#endif
+        if (!split) {
+            store_query(st, p, tok, head, lane, valid);
+            __builtin_amdgcn_wave_barrier();
         }
-        store_query(st, p, tok, head, lane, valid);
-        __builtin_amdgcn_wave_barrier();
+    }
+    if (split) {
+        // merge the key-split partials: waves with part > 0 park (max, partial sum, O^T) in the K region (all key loops are done)
+        __syncthreads();
+        float* mb = reinterpret_cast<float*>(k_lds);
+        if (part > 0) {
+            float* w = mb + (size_t)(wave - ntq) * 34 * 64 + lane;
+            w[0] = st.m; w[64] = st.l;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) w[(2 + dt * 16 + r) * 64] = st.o[dt][r];
+        }
+        __syncthreads();
+        if (part == 0) {
+            for (int pp = 1; pp < nsplit; ++pp) {
+                const float* rd = mb + (size_t)(wave + pp * ntq - ntq) * 34 * 64 + lane;
+                const float m2 = rd[0], l2 = rd[64];
+                const float m_new = fmaxf(st.m, m2);
+                const float a1 = __builtin_amdgcn_exp2f((st.m - m_new) * c_exp), a2 = __builtin_amdgcn_exp2f((m2 - m_new) * c_exp);
+                st.l = st.l * a1 + l2 * a2;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.o[dt][r] = st.o[dt][r] * a1 + rd[(2 + dt * 16 + r) * 64] * a2;
+                st.m = m_new;
+            }
+            store_query(st, p, tok, head, lane, valid);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Global attention: one workgroup per (image, head, 128-query block); K / V^T streamed through a
-// double-buffered LDS ring, 2 key tiles (64 MFMA rows) per stage, next stage's global loads issued
-// before the current stage's MFMAs.
+// Global attention: one workgroup per (image, head, 128-query block); K rows and row-major V rows streamed through a
+// double-buffered LDS ring (register staged: global -> VGPR -> ds_write_b128, both in the same 16-B chunks, V read back
+// transposed with ds_read_b64_tr_b16 like the windowed kernel), 2 key tiles (64 MFMA rows) per stage, next stage's global
+// loads issued before the current stage's MFMAs.  OCC = 3 for the 32 x 32 window: 172 VGPRs without the V^T transposition's
+// staging registers and 49.7 KB of LDS let three workgroups share a CU (in-model 0.437 -> 0.412 ms / step at B = 16,
+// profiles/r04_attention_dma_tr.txt).  LDS-DMA is not used here: the compiler puts a vmcnt(0) in front of every LDS read
+// while a DMA is in flight, which would serialise the ring.
 // ---------------------------------------------------------------------------------------------
-template <int WIN>
-__global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
+template <int WIN, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
     constexpr int NT = Geom<WIN>::NT, WP = Geom<WIN>::WP, RPT = Geom<WIN>::RPT;
     constexpr int STAGE = 2 * 4096 + 2 * 4096;   // 2 K tiles + 2 V^T tiles
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * 32 * (WP + 1) * 4];
@@ -518,9 +560,8 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
 
     // staging registers (named, not arrays: hipcc keeps lambda-captured staging arrays in scratch):
     // 2 K chunks per thread, one 4-key x 8-dim V block for threads < 128
-    uint4 rk0, rk1, rv0, rv1, rv2, rv3;
-    const int s_c = tid & 7, s_i = (tid >> 3) & 31;                 // K item: chunk, row (tile = e)
-    const int s_dc = tid & 7, s_kq = (tid >> 3) & 7, s_tl = tid >> 6;  // V item (tid < 128)
+    uint4 rk0, rk1, rv0, rv1;
+    const int s_c = tid & 7, s_i = (tid >> 3) & 31;                 // K and V item: chunk, row (tile = e)
     // Staging loads as buffer loads: the per-thread offsets are loop-invariant VGPRs and the stage advances a scalar
     // offset, so the key loop carries no address arithmetic on the (binding) VALU.  Offsets are relative to the image's
     // first token: S*S*ld*2 bytes < 2^31 for every supported S.
@@ -528,16 +569,19 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qkv + tok0 * p.ld), 0, 0x7fffffff, 0x00020000);
     const int ldb = p.ld * 2;
     const int ko0 = s_i * ldb + (D + head * HD + s_c * 8) * 2, ko1 = ko0 + 32 * ldb;
-    const int vo0 = (s_tl * 32 + s_kq * 4) * ldb + (2 * D + head * HD + s_dc * 8) * 2;
-    const int vo1 = vo0 + ldb, vo2 = vo0 + 2 * ldb, vo3 = vo0 + 3 * ldb;
+    const int vo0 = ko0 + D * 2, vo1 = ko1 + D * 2;
+    const int kslot = s_i * 128 + swz8(s_i, s_c) * 16;              // K rows: read_kfrag's swizzle
+    const int vslot = s_i * 128 + ((s_c ^ (((s_i >> 1) & 1) * 4)) * 16);   // row-major V rows: the ds_read_b64_tr_b16 swizzle (vtr_bases)
+    int vb0, vb1;
+    vtr_bases(lane, vb0, vb1);
 #define SRH_LD128(dst, vo, so) { const u32x4 t_ = __builtin_amdgcn_raw_buffer_load_b128(rsq, vo, so, 0); dst = make_uint4(t_[0], t_[1], t_[2], t_[3]); }
 #define SRH_LOAD_STAGE(sidx) { const int so_ = (sidx) * 64 * ldb; \
-        SRH_LD128(rk0, ko0, so_) SRH_LD128(rk1, ko1, so_) \
-        if (tid < 128) { SRH_LD128(rv0, vo0, so_) SRH_LD128(rv1, vo1, so_) SRH_LD128(rv2, vo2, so_) SRH_LD128(rv3, vo3, so_) } }
+        SRH_LD128(rk0, ko0, so_) SRH_LD128(rk1, ko1, so_) SRH_LD128(rv0, vo0, so_) SRH_LD128(rv1, vo1, so_) }
 #define SRH_STORE_STAGE(buf) { char* base_ = smem + (buf) * STAGE; \
-        *reinterpret_cast<uint4*>(base_ + s_i * 128 + swz8(s_i, s_c) * 16) = rk0; \
-        *reinterpret_cast<uint4*>(base_ + 4096 + s_i * 128 + swz8(s_i, s_c) * 16) = rk1; \
-        if (tid < 128) vt_write(base_ + 8192 + s_tl * 4096, s_kq, s_dc, rv0, rv1, rv2, rv3); }
+        *reinterpret_cast<uint4*>(base_ + kslot) = rk0; \
+        *reinterpret_cast<uint4*>(base_ + 4096 + kslot) = rk1; \
+        *reinterpret_cast<uint4*>(base_ + 8192 + vslot) = rv0; \
+        *reinterpret_cast<uint4*>(base_ + 12288 + vslot) = rv1; }
 
     const float c_exp = p.scale * 1.4426950408889634f;
     constexpr int NSTAGE = NT / 2;
@@ -558,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnParams p) {
             read_kfrag(kfB, base + 4096, lane); \
             const float rh0a = rhp[((buf) * 2) * RPT], rh1a = RPT == 2 ? rhp[((buf) * 2) * RPT + 1] : 0.f; \
             const float rh0b = rhp[((buf) * 2 + 1) * RPT], rh1b = RPT == 2 ? rhp[((buf) * 2 + 1) * RPT + 1] : 0.f; \
-            attn_tile2<WIN>(st, kfA, kfB, base + 8192, base + 8192 + 4096, rh0a, rh1a, rh0b, rh1b, c_exp, lane); \
+            attn_tile2<WIN>(st, kfA, kfB, base + 8192, base + 8192 + 4096, vb0, vb1, rh0a, rh1a, rh0b, rh1b, c_exp, lane); \
         } \
         if (p.ablate != 2 && p.ablate != 8) SRH_STORE_STAGE((buf) ^ 1) \
         if (p.ablate != 8) __syncthreads(); }
@@ -685,6 +729,16 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     }
 }
 
+// hipFuncSetAttribute is per device: once per (kernel group, device) of the process
+static bool first_use_on_device(unsigned& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
 #ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): ablation switches change the RESULT
@@ -694,18 +748,16 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     p.ablate = 0;
 #endif
     const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32)));
-    static const bool use_hdx = !(getenv("SRH_ATTN_HDX") && atoi(getenv("SRH_ATTN_HDX")) == 0);
-    if (!mfma_path && use_hdx && attention_hdx_supported(p)) return launch_attention_hdx(p, s);
+    if (!mfma_path && attention_hdx_supported(p)) return launch_attention_hdx(p, s);
     if (!mfma_path) {      // other head dims / windows (ViT-H at 512 px, the 64x64 global window of 1024-pixel tiles)
         if ((p.hd != 64 && p.hd != 80) || !p.table_h || !p.table_w || p.win > 64) return -2;
         const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
         const int lds = (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 6 + 256 * 2 * p.win * 4;
         if (lds > 160 * 1024) return -2;
-        static bool gattr = false;
-        if (!gattr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            gattr = true;
+        static unsigned gattr = 0;
+        if (first_use_on_device(gattr)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         const dim3 grid(p.B * nw * nw * p.heads * nqb);
         if (p.hd == 64) hipLaunchKernelGGL(attn_generic_kernel<8>, grid, dim3(256), lds, s, p);
@@ -714,16 +766,14 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     }
     if (p.win == p.S) {
         const int grid = p.B * p.heads * (p.S * p.S / 128);
-        if (p.S == 32) hipLaunchKernelGGL(attn_global_kernel<32>, dim3(grid), dim3(256), 0, s, p);
-        else if (p.S == 16) hipLaunchKernelGGL(attn_global_kernel<16>, dim3(grid), dim3(256), 0, s, p);
+        if (p.S == 32 && p.ablate != 9) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 2>), dim3(grid), dim3(256), 0, s, p);   // probe builds: two workgroups / CU
+        else if (p.S == 16) hipLaunchKernelGGL((attn_global_kernel<16, 2>), dim3(grid), dim3(256), 0, s, p);
         else return -2;
     } else if (p.win == 14) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
-            attr_set = true;
-        }
+        static unsigned wattr = 0;
+        if (first_use_on_device(wattr))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
         const int nw = (p.S + 13) / 14;
         hipLaunchKernelGGL(attn_window_kernel, dim3(p.B * nw * nw * p.heads), dim3(256), WIN_LDS, s, p);
     } else {

@@ -83,7 +83,10 @@ __device__ __forceinline__ float hx_tile_exp(const f32x16& s, float rh0, float r
 
 template <int KS, int NDT>
 __device__ __forceinline__ float hx_update_max(QStateX<KS, NDT>& st, float mloc, float c_exp) {
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    {   // max over both 32-lane halves: v_permlane32_swap_b32 (VALU) instead of a ds_bpermute round trip
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+        mloc = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
     const float m_new = fmaxf(st.m, mloc);
     if (__any(m_new != st.m)) {
         const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c_exp);
@@ -293,7 +296,8 @@ __global__ __launch_bounds__(256, WIN == 14 ? 2 : 1) void attn_hdx_kernel(AttnPa
             read_kf(kfa, NT - 1);
             hx_tile<WIN, KS, NDT>(st, kfa, vt_lds + (NT - 1) * VTT, rhq[(NT - 1) * RPT], rhq[(NT - 1) * RPT + 1], c_exp, lane);
         }
-        const float inv = 1.0f / (st.l + __shfl_xor(st.l, 32, 64));
+        const auto lr = __builtin_amdgcn_permlane32_swap(__float_as_uint(st.l), __float_as_uint(st.l), false, false);
+        const float inv = 1.0f / (__uint_as_float(lr[0]) + __uint_as_float(lr[1]));
         if (valid) {
             f16* o = p.out + tok * p.ldo + head * HD;
 #pragma unroll
@@ -317,10 +321,12 @@ template <int HD, int WIN>
 int hdx_launch(const AttnParams& p, hipStream_t s) {
     constexpr int NDT = (HD + 31) / 32, NT = GeomX<WIN>::NT;
     constexpr int lds = NT * 32 * HD * 2 + NT * HD * 64 + (32 * NDT - HD) * 64 + 4 * 32 * (WIN + 1) * 4;   // WIN 14: 78.5 KiB = two per CU
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;                                     // per device of the process (the attribute is per device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr & (1u << (dev & 31)))) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_hdx_kernel<HD, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
+        attr |= 1u << (dev & 31);
     }
     const int nw = WIN == 14 ? (p.S + WIN - 1) / WIN : 1;
     const int grid = p.B * p.heads * nw * nw;

@@ -1,0 +1,88 @@
+// Attention probe: the windowed (LDS-DMA / ds_read_b64_tr_b16 / key split) and global kernels of attention.hip timed alone at the
+// bench shape, with the ablation switches of a SRH_TUNING build (1 no key loop, 2 no K/V staging, 3 no rel-pos, 5 no key split,
+// 7 return at once, 8 key loops x 4, 9 global kernel at two workgroups / CU).  The key split changes the rounding of the edge /
+// corner windows only: outputs with and without it are compared.  (The comparison against the round-3 kernels — register staging,
+// v_perm transposition — that this probe made before they were removed is profiles/r04_attention_dma_tr.txt.)
+// Build: tools/probes/build_probes.sh.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+#include "../../sam_road_amd/csrc/common.hpp"
+#include "../../sam_road_amd/csrc/kernels.hpp"
+using namespace srh;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+static float run(AttnParams p, int abl, int reps, hipStream_t st) {
+    p.ablate = abl;
+    for (int i = 0; i < 3; ++i) launch_attention(p, st);
+    CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_attention(p, st);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fminf(best, ms * 1e3f / reps);
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 16, S = argc > 2 ? atoi(argv[2]) : 32, heads = 12, D = heads * 64;
+    const size_t T = (size_t)B * S * S;
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<f16> qkv(T * 3 * D), bias(3 * D), th(63 * 64), tw(63 * 64);
+    for (auto& v : qkv) v = (f16)(nd(rng) * 1.5f);
+    for (auto& v : bias) v = (f16)(nd(rng) * 0.5f);
+    for (auto& v : th) v = (f16)(nd(rng) * 0.3f);
+    for (auto& v : tw) v = (f16)(nd(rng) * 0.3f);
+    f16 *dq, *db, *dh, *dw, *o0, *o1;
+    CK(hipMalloc(&dq, qkv.size() * 2)); CK(hipMalloc(&db, bias.size() * 2)); CK(hipMalloc(&dh, th.size() * 2)); CK(hipMalloc(&dw, tw.size() * 2));
+    CK(hipMalloc(&o0, T * D * 2)); CK(hipMalloc(&o1, T * D * 2));
+    CK(hipMemcpy(dq, qkv.data(), qkv.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(db, bias.data(), bias.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dh, th.data(), th.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, tw.data(), tw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(o0, 0, T * D * 2)); CK(hipMemset(o1, 0xff, T * D * 2));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    AttnParams p;
+    p.qkv = dq; p.ld = 3 * D; p.table_h = dh; p.table_w = dw; p.bias_qkv = db; p.ldo = D; p.B = B; p.S = S; p.heads = heads; p.hd = 64; p.win = 14;
+    p.scale = 0.125f;
+    // outputs: with and without the key split
+    p.out = o0; p.ablate = 5; if (launch_attention(p, st)) { printf("launch failed\n"); return 1; }
+    p.out = o1; p.ablate = 0; if (launch_attention(p, st)) { printf("launch failed\n"); return 1; }
+    CK(hipStreamSynchronize(st));
+    std::vector<f16> h0(T * D), h1(T * D);
+    CK(hipMemcpy(h0.data(), o0, T * D * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o1, T * D * 2, hipMemcpyDeviceToHost));
+    double md[3] = {0, 0, 0}; size_t nd_[3] = {0, 0, 0}, nn[3] = {0, 0, 0}; double ref_max = 0; size_t nanc = 0;
+    for (size_t t = 0; t < T; ++t) {
+        const int y = (t / S) % S, x = t % S;
+        const int wy = y / 14, wx = x / 14;
+        const int nry = std::min(14, S - wy * 14), nrx = std::min(14, S - wx * 14);
+        const int cls = (nry * nrx > 64) ? 0 : (nry * nrx > 32 ? 1 : 2);
+        for (int d = 0; d < D; ++d) {
+            const float a = (float)h0[t * D + d], b = (float)h1[t * D + d];
+            if (std::isnan(b)) ++nanc;
+            md[cls] = std::max(md[cls], (double)fabsf(a - b)); nd_[cls] += (a != b); ++nn[cls];
+            ref_max = std::max(ref_max, (double)fabsf(a));
+        }
+    }
+    printf("B=%d S=%d  max|out|=%.3f  NaN=%zu\n", B, S, ref_max, nanc);
+    const char* names[3] = {"full (>2 query tiles)", "edge (2 query tiles)", "corner (1 query tile)"};
+    for (int c = 0; c < 3; ++c) printf("  %-24s max |split - unsplit| = %.3e   values differing %zu of %zu\n", names[c], md[c], nd_[c], nn[c]);
+    p.out = o1;
+    for (int rep = 0; rep < 2; ++rep)
+        printf("  windowed:  full %6.1f us   no key loop %6.1f   no staging %6.1f   no rel-pos %6.1f   no key split %6.1f   launch floor %6.1f\n",
+               run(p, 0, 10, st), run(p, 1, 10, st), run(p, 2, 10, st), run(p, 3, 10, st), run(p, 5, 10, st), run(p, 7, 10, st));
+    { const float t0_ = run(p, 0, 10, st), t8_ = run(p, 8, 10, st);
+      printf("  windowed:  key loops x 4 %6.1f us -> the key loops alone cost %6.1f us of %6.1f\n", t8_, (t8_ - t0_) / 3, t0_); }
+    AttnParams g = p; g.win = S;
+    for (int rep = 0; rep < 2; ++rep)
+        printf("  global:    full %6.1f us   two workgroups / CU %6.1f   no key loop %6.1f   no staging %6.1f\n",
+               run(g, 0, 10, st), run(g, 9, 10, st), run(g, 1, 10, st), run(g, 2, 10, st));
+    return 0;
+}

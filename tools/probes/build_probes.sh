@@ -15,6 +15,13 @@ done
 $HIPCC $FLAGS -c tools/probes/gemm_probe.hip -o tools/probes/build/gemm_probe.o &
 wait
 $HIPCC --offload-arch=gfx950 tools/probes/build/gemm_probe.o tools/probes/build/gemm.o tools/probes/build/gemm_q192.o tools/probes/build/gemm_z192.o -o tools/probes/gemm_probe
+# windowed-attention probe: old vs new kernel of attention.hip (SRH_TUNING: the ablation switches and the old kernel behind ablate += 16)
+for f in attention attention_hdx; do
+  $HIPCC $FLAGS -fno-honor-nans -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
+done
+$HIPCC $FLAGS -c tools/probes/attn_win_probe.hip -o tools/probes/build/attn_win_probe.o &
+wait
+$HIPCC --offload-arch=gfx950 tools/probes/build/attn_win_probe.o tools/probes/build/attention.o tools/probes/build/attention_hdx.o -o tools/probes/attn_win_probe
 for p in feed_probe pipe_probe mfma_probe dma_probe feedx_probe mfma_data_probe; do
   [ -f tools/probes/$p.hip ] && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p
 done

@@ -239,7 +239,8 @@ class ZGen:
         p.v_lshlrev_b32(t3, 4, LANE)
         p.v_add_u32(VBD, T2, t3)
         p.v_mov_b32(VC0, float(GELU_C[0]))
-        p.v_mov_b32(VC0P[0], float(GELU_C[0]))
+        if self.sched.get("gelu_pk"):
+            p.v_mov_b32(VC0P[0], float(GELU_C[0]))
         # tiles of this workgroup: idx = bid, bid + grid, ...; my_tiles = ceil((ntiles - bid) / grid)   (bid < ntiles)
         p.s_sub_u32(T0, NTILES, BID)
         p.s_add_u32(T0, T0, GRID)

@@ -119,8 +119,9 @@ __device__ __forceinline__ float update_max(QState& st, float mloc, float c_exp)
         mloc = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     }
     const float m_new = fmaxf(st.m, mloc);
-    // rescale the running state only when some lane's max moved (wave-uniform branch; after the first
-    // few key tiles the max is usually stable and the 32 accumulator multiplies are skipped)
+    // rescale the running state only when some lane's max moved (wave-uniform branch).  (A LAZY rule — move the reference only when
+    // a row maximum has outgrown it by 2^8, P up to 2^8 — was measured in round 4: with 32 rows per tile some maximum moves in
+    // nearly every 64-key step, yet skipping the 17 packed multiplies bought nothing measurable, profiles/r04_attention_asm_global.txt.)
     if (__any(m_new != st.m)) {
         const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c_exp);
         st.l *= alpha;
@@ -202,7 +203,7 @@ __device__ __forceinline__ void store_query(const QState& st, const AttnParams& 
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(st.l), __float_as_uint(st.l), false, false);
         lsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-    const float inv = 1.0f / lsum;
+    const float inv = __builtin_amdgcn_rcpf(lsum);               // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
     if (!valid) return;
     f16* o = p.out + tok * p.ldo + head * HD;
 #pragma unroll
@@ -765,8 +766,11 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     if (p.win == p.S) {
+#ifdef SRH_G64_PROBE   // tools/probes only: the generated-asm global kernel (tools/probes/attention_g64.hip), 9 / 10 = the HIP kernel
+        if (p.ablate != 9 && p.ablate != 10 && attention_g64_supported(p)) return launch_attention_g64(p, s);
+#endif
         const int grid = p.B * p.heads * (p.S * p.S / 128);
-        if (p.S == 32 && p.ablate != 9) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
+        if (p.S == 32 && p.ablate != 10) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
         else if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 2>), dim3(grid), dim3(256), 0, s, p);   // probe builds: two workgroups / CU
         else if (p.S == 16) hipLaunchKernelGGL((attn_global_kernel<16, 2>), dim3(grid), dim3(256), 0, s, p);
         else return -2;

@@ -216,6 +216,19 @@ class Prog:
     def s_sub_u32(self, d, a, b):
         self._s_bin("s_sub_u32", lambda x, y: x - y, d, a, b, scc=lambda x, y, r: y > x)
 
+    def s_min_u32(self, d, a, b):
+        self._s_bin("s_min_u32", lambda x, y: min(int(x), int(y)), d, a, b)
+
+    def s_addc_u32(self, d, a, b):
+        """d = a + b + scc (carry in); scc = carry out"""
+        a, b = self._lit(a), self._lit(b)
+
+        def emu(st):
+            v = int(self._sval(st, a)) + int(self._sval(st, b)) + int(st.scc)
+            self._swrite(st, d, v)
+            st.scc = 1 if v > 0xFFFFFFFF else 0
+        self.add(f"s_addc_u32 {d}, {a}, {b}", emu, "salu", [a, b], [d])
+
     def s_mul_i32(self, d, a, b):
         self._s_bin("s_mul_i32", lambda x, y: x * y, d, a, b)
 
@@ -442,6 +455,74 @@ class Prog:
     def v_max_f32(self, d, a, b):
         self._v_op("v_max_f32", lambda x, y: self._u(np.fmax(self._f(x), self._f(y))), d, [a, b])
 
+    def v_sub_f32(self, d, a, b):
+        self._v_op("v_sub_f32", lambda x, y: self._u(self._f(x) - self._f(y)), d, [a, b])
+
+    def v_max3_f32(self, d, a, b, c):
+        self._v_op("v_max3_f32", lambda x, y, z: self._u(np.fmax(np.fmax(self._f(x), self._f(y)), self._f(z))), d, [a, b, c])
+
+    def v_min_u32(self, d, a, b):
+        self._v_op("v_min_u32", lambda x, y: np.minimum(x, y), d, [a, b])
+
+    def v_rcp_f32(self, d, a):
+        with np.errstate(divide="ignore"):
+            self._v_op("v_rcp_f32", lambda x: self._u((1.0 / self._f(x).astype(np.float64)).astype(np.float32)), d, [a], kind="trans")
+
+    def v_pk_add_f32(self, d, a, b):
+        """d.lo = a.lo + b.lo, d.hi = a.hi + b.hi on 64-bit register pairs"""
+        assert d.n == 2 and a.n == 2 and b.n == 2
+
+        def emu(st):
+            for h in range(2):
+                self._vwrite(st, d[h], self._u(self._f(self._vsrc(st, a[h])) + self._f(self._vsrc(st, b[h]))))
+        self.add(f"v_pk_add_f32 {d}, {a}, {b}", emu, "valu", [a, b], [d])
+
+    def v_pk_mul_f32(self, d, a, b, bcast_a=False):
+        """d.lo = a.lo * b.lo, d.hi = a.hi * b.hi; bcast_a: a's LOW dword feeds both halves (op_sel_hi:[0,1])"""
+        assert d.n == 2 and a.n == 2 and b.n == 2
+
+        def emu(st):
+            lo = self._f(self._vsrc(st, a[0])) * self._f(self._vsrc(st, b[0]))
+            hi = self._f(self._vsrc(st, a[0 if bcast_a else 1])) * self._f(self._vsrc(st, b[1]))
+            self._vwrite(st, d[0], self._u(lo))
+            self._vwrite(st, d[1], self._u(hi))
+        self.add(f"v_pk_mul_f32 {d}, {a}, {b}" + (" op_sel_hi:[0,1]" if bcast_a else ""), emu, "valu", [a, b], [d])
+
+    def v_cmp_neq_f32(self, a, b):
+        """vcc = !(a == b) per lane (true for unordered)"""
+        a, b = self._lit(a), self._lit(b)
+
+        def emu(st):
+            m = ~(self._f(self._vsrc(st, a)) == self._f(self._vsrc(st, b)))
+            st.special["vcc"] = int(sum(1 << i for i in range(64) if m[i]))
+        self.add(f"v_cmp_neq_f32 vcc, {a}, {b}", emu, "valu", [a, b], [VCC])
+
+    def v_cmp_lt_f32(self, a, b):
+        """vcc = a < b per lane (false for unordered); VOPC: a may be an SGPR / inline constant, b is a VGPR"""
+        a, b = self._lit(a), self._lit(b)
+
+        def emu(st):
+            with np.errstate(invalid="ignore"):
+                m = self._f(self._vsrc(st, a)) < self._f(self._vsrc(st, b))
+            st.special["vcc"] = int(sum(1 << i for i in range(64) if m[i]))
+        self.add(f"v_cmp_lt_f32 vcc, {a}, {b}", emu, "valu", [a, b], [VCC])
+
+    def v_cmp_gt_f32(self, a, b):
+        """vcc = a > b per lane (false for unordered)"""
+        a, b = self._lit(a), self._lit(b)
+
+        def emu(st):
+            with np.errstate(invalid="ignore"):
+                m = self._f(self._vsrc(st, a)) > self._f(self._vsrc(st, b))
+            st.special["vcc"] = int(sum(1 << i for i in range(64) if m[i]))
+        self.add(f"v_cmp_gt_f32 vcc, {a}, {b}", emu, "valu", [a, b], [VCC])
+
+    def s_cbranch_vccz(self, label):
+        self.add(f"s_cbranch_vccz {label}", lambda st: label if st.special["vcc"] == 0 else None, "branch", [VCC], [])
+
+    def s_cbranch_vccnz(self, label):
+        self.add(f"s_cbranch_vccnz {label}", lambda st: label if st.special["vcc"] != 0 else None, "branch", [VCC], [])
+
     def v_fma_f32(self, d, a, b, c):
         def fn(x, y, z):
             return self._u((self._f(x).astype(np.float64) * self._f(y).astype(np.float64) + self._f(z).astype(np.float64)).astype(np.float32))
@@ -610,7 +691,112 @@ class Prog:
             st.issue_lgkm(lambda: None)
         self.add(f"ds_write_b128 {addr}, {data}" + (f" offset:{offset}" if offset else ""), emu, "ds", [addr, data], [])
 
+    def _ds_read_n(self, name, nbytes, d, addr, offset, post=None):
+        """nbytes (4 / 8) per lane; post(bytes[64, nbytes]) -> dwords[64, nbytes / 4] (the transposed read permutes across lanes)"""
+        ndw = nbytes // 4
+        assert d.n == ndw and 0 <= offset <= 65535 and offset % nbytes == 0
+
+        def emu(st):
+            ad = st.v[addr.idx].astype(np.int64) + offset
+            assert (ad % nbytes == 0).all() and (ad >= 0).all() and (ad + nbytes <= st.wg.lds.size).all(), name + " address"
+
+            def sample():
+                raw = st.wg.lds[ad[:, None] + np.arange(nbytes)[None, :]].reshape(64, nbytes).copy()
+                if post is not None:
+                    raw = post(raw)
+                return raw.view(np.uint32).reshape(64, ndw)
+            tgt = st.v if d.file == "v" else st.a
+            if st.wg.ds_lazy:
+                for i in range(ndw):
+                    tgt[d.idx + i] = np.full(64, POISON, np.uint32)
+                box = {"w": None}
+
+                def sample_now():
+                    if box["w"] is None:
+                        box["w"] = sample()
+
+                def deliver():
+                    sample_now()
+                    for i in range(ndw):
+                        tgt[d.idx + i] = box["w"][:, i].copy()
+                deliver.sample_now = sample_now
+                st.issue_lgkm(deliver)
+            else:
+                w = sample()
+                for i in range(ndw):
+                    tgt[d.idx + i] = w[:, i].copy()
+                st.issue_lgkm(lambda: None)
+        self.add(f"{name} {d}, {addr}" + (f" offset:{offset}" if offset else ""), emu, "ds", [addr], [d])
+
+    def ds_read_b32(self, d, addr, offset=0):
+        self._ds_read_n("ds_read_b32", 4, d, addr, offset)
+
+    def ds_read_b64(self, d, addr, offset=0):
+        self._ds_read_n("ds_read_b64", 8, d, addr, offset)
+
+    def ds_read_b64_tr_b16(self, d, addr, offset=0):
+        """Transposed read: in every 16-lane group, lane i hands in the address of 4 consecutive 16-bit values D_i[0..3];
+        lane c of the group receives element j = D_{4j + c/4}[c % 4] (a [4][16] block: lane c gets column c)."""
+        def post(raw):
+            h = raw.view(np.uint16).reshape(4, 16, 4)             # [group, lane i, element]
+            out = np.empty_like(h)
+            for c in range(16):
+                for j in range(4):
+                    out[:, c, j] = h[:, 4 * j + c // 4, c % 4]
+            return out.reshape(64, 4).view(np.uint8).reshape(64, 8)
+        self._ds_read_n("ds_read_b64_tr_b16", 8, d, addr, offset, post)
+
+    def ds_write_b32(self, addr, data, offset=0):
+        assert data.n == 1 and 0 <= offset <= 65535 and offset % 4 == 0
+
+        def emu(st):
+            st.flush_ds_reads()
+            ad = st.v[addr.idx].astype(np.int64) + offset
+            assert (ad % 4 == 0).all() and (ad >= 0).all() and (ad + 4 <= st.wg.lds.size).all(), "ds_write_b32 address"
+            src = st.v if data.file == "v" else st.a
+            w = src[data.idx].copy().view(np.uint8).reshape(64, 4)
+            for l in np.nonzero(st.exec_mask())[0]:
+                st.wg.lds[ad[l]:ad[l] + 4] = w[l]
+            st.issue_lgkm(lambda: None)
+        self.add(f"ds_write_b32 {addr}, {data}" + (f" offset:{offset}" if offset else ""), emu, "ds", [addr, data], [])
+
     # ---------------------------------------------------------------------------------------- VMEM
+    @staticmethod
+    def _rsrc_base(st, rsrc):
+        """Kernarg pointers are 0 in the emulator (the SGPR pair carries the numpy buffer as a tag): the numeric base of a resource is
+        whatever the program ADDED to the pointer, i.e. a byte offset into the tagged buffer."""
+        return int(st.s[rsrc.idx]) | ((int(st.s[rsrc.idx + 1]) & 0xFFFF) << 32)
+
+    def tag_copy(self, d, s_):
+        """Emulator only: SGPR d now points into the buffer that SGPR s_ is tagged with (pointer arithmetic keeps the numeric offset)."""
+        def emu(st):
+            st.sobj[d.idx] = st.sobj[s_.idx]
+        self.add(f"; {d} points into the buffer of {s_}", emu, "comment")
+
+    def buffer_load_dwordx4(self, d, voff, rsrc, soff, offset=0):
+        """buffer_load_dwordx4 d, voff, rsrc, soff offen [offset:imm]: 16 B per lane into VGPRs or AGPRs (delivered at the retiring vmcnt)."""
+        assert d.n == 4 and rsrc.n == 4 and 0 <= offset < 4096
+
+        def emu(st):
+            buf = st.sobj[rsrc.idx]
+            nrec = int(st.s[rsrc.idx + 2])
+            base = self._rsrc_base(st, rsrc)
+            off = st.v[voff.idx].astype(np.int64) + int(st.s[soff.idx]) + offset
+            m = st.exec_mask()
+            assert (off[m] >= 0).all() and (off[m] + 16 <= min(nrec, buf.size - base)).all(), "buffer_load out of range"
+            data = np.zeros((64, 16), np.uint8)
+            data[m] = buf[(base + off[m][:, None] + np.arange(16)[None, :])]
+            w = data.view(np.uint32).reshape(64, 4)
+            tgt = st.v if d.file == "v" else st.a
+            for i in range(4):
+                tgt[d.idx + i] = np.full(64, POISON, np.uint32)
+
+            def deliver():
+                for i in range(4):
+                    tgt[d.idx + i] = w[:, i].copy()
+            st.issue_vm(deliver)
+        self.add(f"buffer_load_dwordx4 {d}, {voff}, {rsrc}, {soff} offen" + (f" offset:{offset}" if offset else ""), emu, "vmem_load", [voff, rsrc, soff], [d])
+
     def buffer_load_lds(self, nbytes, voff, rsrc, soff):
         """buffer_load_dword{,x4} voff, rsrc, soff offen lds: every active lane moves nbytes from
         base + voff + soff to LDS[M0 + lane * nbytes]."""
@@ -619,15 +805,16 @@ class Prog:
         def emu(st):
             buf = st.sobj[rsrc.idx]
             nrec = int(st.s[rsrc.idx + 2])
+            base = self._rsrc_base(st, rsrc)
             off = st.v[voff.idx].astype(np.int64) + int(st.s[soff.idx])
             m = st.exec_mask()
-            assert (off[m] >= 0).all() and (off[m] + nbytes <= min(nrec, buf.size)).all(), \
-                f"LDS-DMA source out of range: max {off[m].max()} + {nbytes} > {min(nrec, buf.size)}"
+            assert (off[m] >= 0).all() and (off[m] + nbytes <= min(nrec, buf.size - base)).all(), \
+                f"LDS-DMA source out of range: max {off[m].max()} + {nbytes} > {min(nrec, buf.size - base)}"
             assert (off[m] % nbytes == 0).all()
             lbase = int(st.special["m0"])
             dst = lbase + np.arange(64, dtype=np.int64) * nbytes
             assert lbase % nbytes == 0 and dst[m].max() + nbytes <= st.wg.lds.size
-            data = buf[(off[m][:, None] + np.arange(nbytes)[None, :])].copy()
+            data = buf[(base + off[m][:, None] + np.arange(nbytes)[None, :])].copy()
             dsel = dst[m]
 
             def land():
@@ -645,7 +832,7 @@ class Prog:
 
         def emu(st):
             buf = st.sobj[rsrc.idx]
-            off = st.v[voff.idx].astype(np.int64) + int(st.s[soff.idx])
+            off = self._rsrc_base(st, rsrc) + st.v[voff.idx].astype(np.int64) + int(st.s[soff.idx])
             m = st.exec_mask()
             assert (off[m] >= 0).all() and (off[m] + 16 <= buf.size).all() and (off[m] % 16 == 0).all(), "store out of range"
             src = st.v if data.file == "v" else st.a

@@ -81,8 +81,26 @@ int main(int argc, char** argv) {
     { const float t0_ = run(p, 0, 10, st), t8_ = run(p, 8, 10, st);
       printf("  windowed:  key loops x 4 %6.1f us -> the key loops alone cost %6.1f us of %6.1f\n", t8_, (t8_ - t0_) / 3, t0_); }
     AttnParams g = p; g.win = S;
-    for (int rep = 0; rep < 2; ++rep)
-        printf("  global:    full %6.1f us   two workgroups / CU %6.1f   no key loop %6.1f   no staging %6.1f\n",
-               run(g, 0, 10, st), run(g, 9, 10, st), run(g, 1, 10, st), run(g, 2, 10, st));
+    {   // global attention: the generated-asm kernel (attention_g64.hip) against the HIP kernel (ablate 9), bit for bit
+        CK(hipMemset(o0, 0, T * D * 2)); CK(hipMemset(o1, 0xff, T * D * 2));
+        g.out = o0; g.ablate = 9; if (launch_attention(g, st)) { printf("launch failed\n"); return 1; }
+        g.out = o1; g.ablate = 0; if (launch_attention(g, st)) { printf("launch failed\n"); return 1; }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(h0.data(), o0, T * D * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o1, T * D * 2, hipMemcpyDeviceToHost));
+        double mdg = 0; size_t ndg = 0, nang = 0;
+        for (size_t i = 0; i < T * D; ++i) {
+            const float a = (float)h0[i], b = (float)h1[i];
+            if (std::isnan(b)) ++nang;
+            mdg = std::max(mdg, (double)fabsf(a - b)); ndg += a != b;
+        }
+        printf("  global: asm vs HIP kernel: max |diff| = %.3e, values differing %zu of %zu, NaN %zu\n", mdg, ndg, T * D, nang);
+        g.out = o1;
+    }
+    printf("  global asm ablations:  no softmax VALU %6.1f us   no MFMA %6.1f   no LDS reads %6.1f   no DMA / barrier %6.1f   MFMAs alone %6.1f   softmax VALU alone %6.1f\n",
+           run(g, 21, 10, st), run(g, 22, 10, st), run(g, 23, 10, st), run(g, 24, 10, st), run(g, 25, 10, st), run(g, 26, 10, st));
+    printf("  global asm:  S^T accumulators in AGPRs (wrong results) %6.1f us (MFMAs alone: %6.1f)   prologue + epilogue only (no key stages) %6.1f\n",
+           run(g, 27, 10, st), run(g, 25, 10, st), run(g, 28, 10, st));
+    for (int rep = 0; rep < 3; ++rep)
+        printf("  global:    asm %6.1f us   HIP (3 workgroups / CU) %6.1f   HIP (2 / CU) %6.1f\n", run(g, 0, 10, st), run(g, 9, 10, st), run(g, 10, 10, st));
     return 0;
 }

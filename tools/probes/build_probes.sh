@@ -8,6 +8,8 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING -Itools/probes/build"
 mkdir -p tools/probes/build
 python3 tools/kgen/gemm_z192_gen.py --variants tools/probes/build   # z192_var{1..6}_act{0,1}.inc: the schedule variants under test
+python3 tools/kgen/attn_g64_gen.py                                  # attn_g64_body.inc / _meta.inc: the asm global attention experiment (probe only)
+python3 tools/kgen/attn_g64_gen.py --variants tools/probes/build    # attn_g64_var{1..8}.inc: its schedule ablations
 mkdir -p tools/probes/build
 for f in gemm gemm_q192 gemm_z192; do
   $HIPCC $FLAGS -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
@@ -17,11 +19,12 @@ wait
 $HIPCC --offload-arch=gfx950 tools/probes/build/gemm_probe.o tools/probes/build/gemm.o tools/probes/build/gemm_q192.o tools/probes/build/gemm_z192.o -o tools/probes/gemm_probe
 # windowed-attention probe: old vs new kernel of attention.hip (SRH_TUNING: the ablation switches and the old kernel behind ablate += 16)
 for f in attention attention_hdx; do
-  $HIPCC $FLAGS -fno-honor-nans -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
+  $HIPCC $FLAGS -DSRH_G64_PROBE -fno-honor-nans -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
 done
+$HIPCC $FLAGS -c tools/probes/attention_g64.hip -o tools/probes/build/attention_g64.o &
 $HIPCC $FLAGS -c tools/probes/attn_win_probe.hip -o tools/probes/build/attn_win_probe.o &
 wait
-$HIPCC --offload-arch=gfx950 tools/probes/build/attn_win_probe.o tools/probes/build/attention.o tools/probes/build/attention_hdx.o -o tools/probes/attn_win_probe
+$HIPCC --offload-arch=gfx950 tools/probes/build/attn_win_probe.o tools/probes/build/attention.o tools/probes/build/attention_g64.o tools/probes/build/attention_hdx.o -o tools/probes/attn_win_probe
 for p in feed_probe pipe_probe mfma_probe dma_probe feedx_probe mfma_data_probe; do
   [ -f tools/probes/$p.hip ] && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p
 done

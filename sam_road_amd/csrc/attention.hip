@@ -157,6 +157,7 @@ __device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size
 template <int WIN, int STRIDE>
 __device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, int qy, int qx, float* buf, int lane) {
     constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
+    static_assert(STRIDE > WIN, "slot WIN of a row is the dump slot");
     const int half = lane >> 5, row = lane & 31;
     const float inv_scale = 1.0f / p.scale;
 #pragma unroll
@@ -176,10 +177,14 @@ __device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, in
                 else for (int e = 0; e < 8; ++e) a[e] = (f16)0.f;
                 acc = mfma32(a, st.q[ks], acc);
             }
+            // P^T[j, q] -> rel[q][k = qc - j + WIN - 1]: one subtract, one unsigned min and an unconditional write per element (k < 0
+            // and k >= WIN — also the zero rows j > 2 WIN - 2 — land in the dump slot WIN) instead of two compares and an exec-masked write
+            const unsigned kb = (unsigned)(qc + WIN - 1 - jt * 32 - 4 * half);
+            float* rowp = buf + row * STRIDE;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = qc - (jt * 32 + mfma32_row(r, lane)) + WIN - 1;
-                if (k >= 0 && k < WIN) buf[row * STRIDE + k] = acc[r] * inv_scale;
+                const unsigned k = kb - (unsigned)((r & 3) + 8 * (r >> 2));
+                rowp[min(k, (unsigned)WIN)] = acc[r] * inv_scale;
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -11,7 +11,7 @@ namespace srh {
 // R rows per wave per iteration (all R rows' loads are issued before any is consumed: the kernel is
 // latency-bound otherwise — PMC showed >90 % of wave cycles parked in s_waitcnt with one row in flight),
 // grid-stride over row groups.
-template <int EPL, int VW, int R>  // elements per lane, vector width (floats), rows per wave per iteration
+template <int EPL, int VW, int R, int NT = 0>  // elements per lane, vector width (floats), rows per wave per iteration, nontemporal x loads (2) / x_out stores (1)
 __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     const int lane = threadIdx.x & 63;
     constexpr int NV = EPL / VW;
@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
             for (int c = 0; c < NV; ++c) {
                 const int off = (c * 64 + lane) * VW;
                 if (VW == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(x + off);
+                    float4 t;
+                    if (NT & 2) { const f32x4 n4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + off)); t = make_float4(n4[0], n4[1], n4[2], n4[3]); }
+                    else t = *reinterpret_cast<const float4*>(x + off);
                     v[r][c * 4 + 0] = t.x; v[r][c * 4 + 1] = t.y; v[r][c * 4 + 2] = t.z; v[r][c * 4 + 3] = t.w;
                 } else {
                     const float2 t = *reinterpret_cast<const float2*>(x + off);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
 #pragma unroll
                     for (int c = 0; c < NV; ++c) {
                         const int off = (c * 64 + lane) * VW;
-                        if (VW == 4) *reinterpret_cast<float4*>(xo + off) = make_float4(v[r][c * 4], v[r][c * 4 + 1], v[r][c * 4 + 2], v[r][c * 4 + 3]);
+                        if (VW == 4) { const float4 t4 = make_float4(v[r][c * 4], v[r][c * 4 + 1], v[r][c * 4 + 2], v[r][c * 4 + 3]); if (NT & 1) { const f32x4 n4 = {t4.x, t4.y, t4.z, t4.w}; __builtin_nontemporal_store(n4, reinterpret_cast<f32x4*>(xo + off)); } else *reinterpret_cast<float4*>(xo + off) = t4; }
                         else *reinterpret_cast<float2*>(xo + off) = make_float2(v[r][c * 2], v[r][c * 2 + 1]);
                     }
                 }
@@ -142,11 +144,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     }
 }
 
-template <int EPL, int VW, int R>
+template <int EPL, int VW, int R, int NT = 0>
 static void launch_ln(const NormParams& p, hipStream_t s) {
     const int groups = (p.M + R - 1) / R;                 // wave-iterations needed
     const int blocks = min((groups + 3) / 4, 256 * 8);    // <= 8 blocks per CU, grid-stride beyond
-    hipLaunchKernelGGL((layernorm_kernel<EPL, VW, R>), dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((layernorm_kernel<EPL, VW, R, NT>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 int launch_layernorm(const NormParams& p, hipStream_t s) {
@@ -154,7 +156,10 @@ int launch_layernorm(const NormParams& p, hipStream_t s) {
     switch (p.D) {
         case 128:  launch_ln<2, 2, 4>(p, s); break;
         case 256:  launch_ln<4, 4, 4>(p, s); break;
-        case 768:  launch_ln<12, 4, 2>(p, s); break;
+        // ViT-B block LayerNorms: one row per wave and iteration, the f32 residual stream read and written with nontemporal hints (it is
+        // touched once per pass; keeping it out of L2 leaves qkv / K / V there for the attention kernels): +0.7 % tiles/s over <12, 4, 2>
+        // with cached accesses, same box, alternating (profiles/r04_layernorm_nt.txt).  Bit-identical output.
+        case 768:  launch_ln<12, 4, 1, 3>(p, s); break;
         case 1024: launch_ln<16, 4, 2>(p, s); break;
         case 1280: launch_ln<20, 4, 2>(p, s); break;
         default: return -2;

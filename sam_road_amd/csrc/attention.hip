@@ -244,9 +244,10 @@ typedef __fp16 h4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int WIN_LDS_K = 7 * 4096, WIN_LDS_V = 7 * 4096, WIN_LDS_TBL = 2 * 4096, WIN_LDS_RH = 4 * 32 * 17 * 4;
 constexpr int WIN_LDS = WIN_LDS_K + WIN_LDS_V + WIN_LDS_TBL + WIN_LDS_RH;     // 74 240 B: two workgroups per CU
 
+template <int AUX = 0>      // AUX 2: nontemporal
 __device__ __forceinline__ void dma16(const void* src, char* lds_wave_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_uniform, 16, 0, AUX);
 }
 
 __device__ __forceinline__ f16x8 tr_read8(const char* a) {
@@ -447,8 +448,9 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
         for (int t = 0; t < 7; ++t) {
             const bool real = (wy * WIN + 2 * t + rr) < S && x < S;
             const f16* row = row0 + t * tstride;
-            dma16(real ? row + D + ck * 8 : padk, k_lds + t * 4096 + wave * 1024);
-            dma16(real ? row + 2 * D + cv * 8 : padv, v_lds + t * 4096 + wave * 1024);
+            // nontemporal: every K / V row is read by exactly one workgroup (+0.3 % tiles/s, profiles/r04_layernorm_nt.txt)
+            dma16<2>(real ? row + D + ck * 8 : padk, k_lds + t * 4096 + wave * 1024);
+            dma16<2>(real ? row + 2 * D + cv * 8 : padv, v_lds + t * 4096 + wave * 1024);
         }
     }
     // (Running the first query tile's rel-pos under the K / V loads — wait for the tables and q only, vmcnt(14) — is not expressible

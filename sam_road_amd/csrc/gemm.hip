@@ -595,16 +595,22 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // (ViT-H fc1 at M = 2048: 640 -> 512 workgroups on 512 slots; measured 46.0 -> 41.3 us).  Not for the few-tile layers: proj / fc2 of
 // ViT-H as 128 tiles x split-K 4 measured no better than 128x128 tiles without / with split-K 3 (profiles/r03_vith_gemm_t160.txt).
 static bool use_tile160(const GemmParams& p) {
+#ifdef SRH_TUNING      // probe builds: A/B switch
     static const bool on = !(getenv("SRH_GEMM_T160") && atoi(getenv("SRH_GEMM_T160")) == 0);
-    if (!on || p.conv_S > 0 || p.pos || p.N % 160 != 0 || p.N % 128 != 0 || p.K % BK != 0 || p.M >= 4096) return false;
+    if (!on) return false;
+#endif
+    if (p.conv_S > 0 || p.pos || p.N % 160 != 0 || p.N % 128 != 0 || p.K % BK != 0 || p.M >= 4096) return false;
     const long t128 = (long)((p.M + 127) / 128) * (p.N / 128), t160 = (long)((p.M + 127) / 128) * (p.N / 160);
     return t128 > 512 && t160 <= 512;
 }
 
 // Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
 int gemm_splitk_factor(const GemmParams& p) {
+#ifdef SRH_TUNING      // probe builds: A/B switch
     static const bool on = !(getenv("SRH_GEMM_SPLITK") && atoi(getenv("SRH_GEMM_SPLITK")) == 0);
-    if (!on || p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
+    if (!on) return 1;
+#endif
+    if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
     if (p.M >= 4096 || q192_preferred(p)) return 1;
     if (use_tile160(p)) return 1;
     const long tiles = (long)(p.M / 128) * (p.N / 128);

@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 3 s sustained leg (sustained_tiles_per_s, SMI clock)")
     ap.add_argument("--no-scene", action="store_true", help="skip the scene block (ms per 2048^2 CityScale scene; tile-sharded over the ranks when N > 1)")
     ap.add_argument("--scenes", type=int, default=16, help="scenes of the scene block's timed stream")
+    ap.add_argument("--scene-timeout", type=float, default=240.0, help="deadline of the scene block in seconds (the line is printed without it afterwards)")
     ap.add_argument("--plumbing-cpu", action="store_true",
                     help="NO measurement: run the N-rank launch contract and the tile-sharded scene block on CPU / gloo with the tests' "
                          "oracle stand-in model (tests/test_distributed_cpu.py) — checks env handling, collectives and the JSON line without a GPU")
@@ -464,12 +465,35 @@ def main():
         out["vs_baseline_def"] = "value / reference_gpu.fp32_eager (reference PyTorch path on the same MI355X, BASELINE.md §3 C2(ii), §5)"
 
     if not args.no_scene and args.workload == "encdec":
-        out_scene = scene_block(args, net, sd, dev, rank, world, distributed)
+        # The scene block must never cost the tiles/s line.  On N > 1 its exchange steps (banded point-to-point canvas reduce, point
+        # broadcast, vote gather) have only ever run on gloo (tests/test_distributed_cpu.py) — gpurun exposes one GPU — so it runs on a
+        # worker thread under a deadline: on an exception or a hang (a rank that failed leaves the others inside a collective) rank 0
+        # still prints the line, with the reason in place of the scene figures, and every rank leaves without the collective teardown.
+        import threading
+        box = {}
+
+        def _scene():
+            try:
+                torch.cuda.set_device(dev)          # the current device is per thread
+                box["scene"] = scene_block(args, net, sd, dev, rank, world, distributed)
+            except Exception as e:      # noqa: BLE001 — reported in the line
+                box["error"] = f"{type(e).__name__}: {e}"[:400]
+        th = threading.Thread(target=_scene, daemon=True)
+        th.start()
+        th.join(timeout=args.scene_timeout)
+        hung = th.is_alive()
         if rank == 0:
-            out["scene"] = out_scene
+            out["scene"] = box.get("scene") if "scene" in box else \
+                {"error": box.get("error", f"no result after {args.scene_timeout:.0f} s (hang in an exchange step?)"), "n_gpus": world}
+        if hung or "error" in box:
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            else:
+                time.sleep(2.0)         # let rank 0's line out before the launcher sees a rank leave
+            os._exit(0)
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
 

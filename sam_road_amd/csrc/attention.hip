@@ -453,8 +453,10 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
             dma16<2>(real ? row + 2 * D + cv * 8 : padv, v_lds + t * 4096 + wave * 1024);
         }
     }
-    // (Running the first query tile's rel-pos under the K / V loads — wait for the tables and q only, vmcnt(14) — is not expressible
-    // here: the compiler puts its own vmcnt(0) in front of every LDS read while any LDS-DMA is in flight.)
+    // (Running the first query tile's rel-pos and the first key tiles under the rest of the K / V DMA was tried with one static LDS
+    // array per DMA group and __builtin_amdgcn_s_waitcnt — the recipe of attn_global_kernel below: the compiler still fenced the
+    // rel_h ds_writes and the key loop's header with vmcnt(0), and three barriers instead of one made it no faster, 0.407-0.412 vs
+    // 0.403-0.408 ms per step.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA writes have landed; all waves' after the barrier
     __syncthreads();
 
@@ -531,24 +533,28 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // Global attention: one workgroup per (image, head, 128-query block); K rows and row-major V rows streamed through a
-// double-buffered LDS ring (register staged: global -> VGPR -> ds_write_b128, both in the same 16-B chunks, V read back
-// transposed with ds_read_b64_tr_b16 like the windowed kernel), 2 key tiles (64 MFMA rows) per stage, next stage's global
-// loads issued before the current stage's MFMAs.  OCC = 3 for the 32 x 32 window: 172 VGPRs without the V^T transposition's
-// staging registers and 49.7 KB of LDS let three workgroups share a CU (in-model 0.437 -> 0.412 ms / step at B = 16,
-// profiles/r04_attention_dma_tr.txt).  LDS-DMA is not used here: the compiler puts a vmcnt(0) in front of every LDS read
-// while a DMA is in flight, which would serialise the ring.
+// double-buffered LDS ring, 2 key tiles (64 MFMA rows) per stage, filled by LDS-DMA one stage ahead (buffer_load ... lds with the
+// stage's scalar offset: no address arithmetic, no staging registers and no ds_write in the loop; wave w moves rows 8w .. 8w+7 of
+// each of the stage's four 32-row tiles K a, K b, V a, V b, swizzles on the source side).  XCD-aware order keeps a head's K / V in
+// one XCD's L2.  158 VGPRs and 49.7 KB of LDS: three workgroups per CU.
+// What makes the DMA ring expressible in HIP (found in round 4): the compiler tracks in-flight LDS-DMA per LDS OBJECT and understands
+// __builtin_amdgcn_s_waitcnt — with every ring stage its own static __shared__ array and the builtin (not inline asm) for the wait,
+// it adds no vmcnt(0) of its own in front of the LDS reads of the other stage.  The rules it imposes: DMA issued in straight-line
+// code (not under a condition), reads of an object that no DMA writes (the rel_h table) only while nothing is in flight — they are
+// taken before the stage's DMA is issued — and one dynamic LDS block or an inline-asm wait fences every LDS read behind all DMA.
+// Against the register-staged ring of round 3 (global -> VGPR -> ds_write): bit-identical, 85.9 -> 79.2 us alone, 0.405 -> 0.366
+// ms per step in the model (profiles/r04_attention_dma_tr.txt).
 // ---------------------------------------------------------------------------------------------
 template <int WIN, int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
     constexpr int NT = Geom<WIN>::NT, WP = Geom<WIN>::WP, RPT = Geom<WIN>::RPT;
-    constexpr int STAGE = 2 * 4096 + 2 * 4096;   // 2 K tiles + 2 V^T tiles
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * 32 * (WP + 1) * 4];
-    float* rh_lds = reinterpret_cast<float*>(smem + 2 * STAGE);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int STAGE = 2 * 4096 + 2 * 4096;   // 2 K tiles + 2 V tiles
+    __shared__ __attribute__((aligned(16))) char ring0[STAGE];
+    __shared__ __attribute__((aligned(16))) char ring1[STAGE];
+    __shared__ __attribute__((aligned(16))) float rh_lds[4 * 32 * (WP + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = p.S, D = p.heads * HD;
     const int nqb = (S * S) / 128;
-    // XCD-aware order (speed only): workgroup u runs on XCD u % 8; give one XCD all nqb query blocks of an
-    // (image, head) back to back so K / V of that head are fetched from HBM once and re-read from its L2.
     int qb, bh;
     {
         const int nbh = p.B * p.heads;
@@ -558,6 +564,18 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
     }
     const int head = bh % p.heads, b = bh / p.heads;
     const size_t tok0 = (size_t)b * S * S;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qkv + tok0 * p.ld), 0, 0x7fffffff, 0x00020000);
+    const int ldb = p.ld * 2;
+    const int r = wave * 8 + (lane >> 3), cpos = lane & 7;
+    const int ko = r * ldb + (D + head * HD) * 2 + ((cpos ^ ((r >> 1) & 7)) * 16);               // read_kfrag's swizzle, source side
+    const int vo = r * ldb + (2 * D + head * HD) * 2 + ((cpos ^ (((r >> 1) & 1) * 4)) * 16);     // the ds_read_b64_tr_b16 swizzle (vtr_bases)
+#define SRH_DMA_STAGE(sidx, ring) { const int so_ = (sidx) * 64 * ldb; char* d_ = (ring) + wave * 1024; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_), 16, ko, so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 4096), 16, ko, so_ + 32 * ldb, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 8192), 16, vo, so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 12288), 16, vo, so_ + 32 * ldb, 0, 0); }
+    SRH_DMA_STAGE(0, ring0)                                        // in flight under the query loads and the rel-pos prologue
 
     const int qi = qb * 128 + wave * 32 + (lane & 31);
     const size_t tok = tok0 + qi;
@@ -565,60 +583,37 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
     load_query<WIN>(st, p, tok, head, lane);
     float* rh = rh_lds + wave * 32 * (WP + 1);
     fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, lane);
-
-    // staging registers (named, not arrays: hipcc keeps lambda-captured staging arrays in scratch):
-    // 2 K chunks per thread, one 4-key x 8-dim V block for threads < 128
-    uint4 rk0, rk1, rv0, rv1;
-    const int s_c = tid & 7, s_i = (tid >> 3) & 31;                 // K and V item: chunk, row (tile = e)
-    // Staging loads as buffer loads: the per-thread offsets are loop-invariant VGPRs and the stage advances a scalar
-    // offset, so the key loop carries no address arithmetic on the (binding) VALU.  Offsets are relative to the image's
-    // first token: S*S*ld*2 bytes < 2^31 for every supported S.
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qkv + tok0 * p.ld), 0, 0x7fffffff, 0x00020000);
-    const int ldb = p.ld * 2;
-    const int ko0 = s_i * ldb + (D + head * HD + s_c * 8) * 2, ko1 = ko0 + 32 * ldb;
-    const int vo0 = ko0 + D * 2, vo1 = ko1 + D * 2;
-    const int kslot = s_i * 128 + swz8(s_i, s_c) * 16;              // K rows: read_kfrag's swizzle
-    const int vslot = s_i * 128 + ((s_c ^ (((s_i >> 1) & 1) * 4)) * 16);   // row-major V rows: the ds_read_b64_tr_b16 swizzle (vtr_bases)
     int vb0, vb1;
     vtr_bases(lane, vb0, vb1);
-#define SRH_LD128(dst, vo, so) { const u32x4 t_ = __builtin_amdgcn_raw_buffer_load_b128(rsq, vo, so, 0); dst = make_uint4(t_[0], t_[1], t_[2], t_[3]); }
-#define SRH_LOAD_STAGE(sidx) { const int so_ = (sidx) * 64 * ldb; \
-        SRH_LD128(rk0, ko0, so_) SRH_LD128(rk1, ko1, so_) SRH_LD128(rv0, vo0, so_) SRH_LD128(rv1, vo1, so_) }
-#define SRH_STORE_STAGE(buf) { char* base_ = smem + (buf) * STAGE; \
-        *reinterpret_cast<uint4*>(base_ + kslot) = rk0; \
-        *reinterpret_cast<uint4*>(base_ + 4096 + kslot) = rk1; \
-        *reinterpret_cast<uint4*>(base_ + 8192 + vslot) = rv0; \
-        *reinterpret_cast<uint4*>(base_ + 12288 + vslot) = rv1; }
 
     const float c_exp = p.scale * 1.4426950408889634f;
     constexpr int NSTAGE = NT / 2;
-    SRH_LOAD_STAGE(0)
-    SRH_STORE_STAGE(0)
-    __syncthreads();
-    // two stages per trip so that the LDS buffer index is a compile-time constant: every ds_read / ds_write address is then
-    // a loop-invariant lane offset plus an immediate (no per-access address VALU in the issue-bound key loop)
     static_assert(NSTAGE % 2 == 0, "the key loop is unrolled by two stages");
     const float* rhp = rh + (lane & 31) * (WP + 1);
-#define SRH_STAGE(sidx, buf) { \
+    // one hand-over per stage: this wave's four pieces have landed (vmcnt(0): nothing else is in flight), the barrier makes that
+    // true for every wave's pieces and says that every wave is done reading the OTHER ring stage — which the next DMA overwrites
+#define SRH_STAGE(sidx, ring, other, rbuf) { \
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     /* vmcnt(0), lgkmcnt / expcnt untouched */ \
+        __builtin_amdgcn_s_barrier(); \
+        asm volatile("" ::: "memory"); \
+        /* rel_h of the stage's two tiles first: rh_lds is not a DMA target, so its reads must come while no DMA is in flight */ \
+        const float rh0a = rhp[((rbuf) * 2) * RPT], rh1a = RPT == 2 ? rhp[((rbuf) * 2) * RPT + 1] : 0.f; \
+        const float rh0b = rhp[((rbuf) * 2 + 1) * RPT], rh1b = RPT == 2 ? rhp[((rbuf) * 2 + 1) * RPT + 1] : 0.f; \
+        asm volatile("" :: "v"(rh0a), "v"(rh1a), "v"(rh0b), "v"(rh1b) : "memory"); \
         const int snext_ = (sidx) + 1 < NSTAGE ? (sidx) + 1 : (sidx);   /* last stage re-loads itself (no branch) */ \
-        if (p.ablate != 2 && p.ablate != 8) SRH_LOAD_STAGE(snext_) \
-        const char* base = smem + (buf) * STAGE; \
+        SRH_DMA_STAGE(snext_, other) \
         if (p.ablate != 1) { \
             f16x8 kfA[4], kfB[4]; \
-            read_kfrag(kfA, base, lane); \
-            read_kfrag(kfB, base + 4096, lane); \
-            const float rh0a = rhp[((buf) * 2) * RPT], rh1a = RPT == 2 ? rhp[((buf) * 2) * RPT + 1] : 0.f; \
-            const float rh0b = rhp[((buf) * 2 + 1) * RPT], rh1b = RPT == 2 ? rhp[((buf) * 2 + 1) * RPT + 1] : 0.f; \
-            attn_tile2<WIN>(st, kfA, kfB, base + 8192, base + 8192 + 4096, vb0, vb1, rh0a, rh1a, rh0b, rh1b, c_exp, lane); \
-        } \
-        if (p.ablate != 2 && p.ablate != 8) SRH_STORE_STAGE((buf) ^ 1) \
-        if (p.ablate != 8) __syncthreads(); }
+            read_kfrag(kfA, ring, lane); \
+            read_kfrag(kfB, ring + 4096, lane); \
+            attn_tile2<WIN>(st, kfA, kfB, ring + 8192, ring + 8192 + 4096, vb0, vb1, rh0a, rh1a, rh0b, rh1b, c_exp, lane); \
+        } }
     for (int sidx = 0; sidx < NSTAGE; sidx += 2) {
-        SRH_STAGE(sidx, 0)
-        SRH_STAGE(sidx + 1, 1)
+        SRH_STAGE(sidx, ring0, ring1, 0)
+        SRH_STAGE(sidx + 1, ring1, ring0, 1)
         rhp += 4 * RPT;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // the tail's re-load of the last stage must not outlive the workgroup's LDS
     store_query(st, p, tok, head, lane, true);
 }
 
@@ -774,11 +769,11 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     }
     if (p.win == p.S) {
 #ifdef SRH_G64_PROBE   // tools/probes only: the generated-asm global kernel (tools/probes/attention_g64.hip), 9 / 10 = the HIP kernel
-        if (p.ablate != 9 && p.ablate != 10 && attention_g64_supported(p)) return launch_attention_g64(p, s);
+        if (p.ablate >= 20 && p.ablate <= 28 && attention_g64_supported(p)) return launch_attention_g64(p, s);        // 20: the asm kernel, 21..28: its ablations
 #endif
         const int grid = p.B * p.heads * (p.S * p.S / 128);
-        if (p.S == 32 && p.ablate != 10) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
-        else if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 2>), dim3(grid), dim3(256), 0, s, p);   // probe builds: two workgroups / CU
+        if (p.S == 32 && p.ablate == 13) hipLaunchKernelGGL((attn_global_kernel<32, 2>), dim3(grid), dim3(256), 0, s, p);        // probe builds: two workgroups / CU
+        else if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
         else if (p.S == 16) hipLaunchKernelGGL((attn_global_kernel<16, 2>), dim3(grid), dim3(256), 0, s, p);
         else return -2;
     } else if (p.win == 14) {

@@ -1,6 +1,6 @@
 // Attention probe: the windowed (LDS-DMA / ds_read_b64_tr_b16 / key split) and global kernels of attention.hip timed alone at the
 // bench shape, with the ablation switches of a SRH_TUNING build (1 no key loop, 2 no K/V staging, 3 no rel-pos, 5 no key split,
-// 7 return at once, 8 key loops x 4, 9 global kernel at two workgroups / CU).  The key split changes the rounding of the edge /
+// 7 return at once, 8 key loops x 4, 13 global kernel at two workgroups / CU, 20 the asm global-attention experiment, 21..28 its ablations).  The key split changes the rounding of the edge /
 // corner windows only: outputs with and without it are compared.  (The comparison against the round-3 kernels — register staging,
 // v_perm transposition — that this probe made before they were removed is profiles/r04_attention_dma_tr.txt.)
 // Build: tools/probes/build_probes.sh.
@@ -83,8 +83,8 @@ int main(int argc, char** argv) {
     AttnParams g = p; g.win = S;
     {   // global attention: the generated-asm kernel (attention_g64.hip) against the HIP kernel (ablate 9), bit for bit
         CK(hipMemset(o0, 0, T * D * 2)); CK(hipMemset(o1, 0xff, T * D * 2));
-        g.out = o0; g.ablate = 9; if (launch_attention(g, st)) { printf("launch failed\n"); return 1; }
-        g.out = o1; g.ablate = 0; if (launch_attention(g, st)) { printf("launch failed\n"); return 1; }
+        g.out = o0; g.ablate = 0; if (launch_attention(g, st)) { printf("launch failed\n"); return 1; }
+        g.out = o1; g.ablate = 20; if (launch_attention(g, st)) { printf("launch failed\n"); return 1; }
         CK(hipStreamSynchronize(st));
         CK(hipMemcpy(h0.data(), o0, T * D * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o1, T * D * 2, hipMemcpyDeviceToHost));
         double mdg = 0; size_t ndg = 0, nang = 0;
@@ -101,6 +101,6 @@ int main(int argc, char** argv) {
     printf("  global asm:  S^T accumulators in AGPRs (wrong results) %6.1f us (MFMAs alone: %6.1f)   prologue + epilogue only (no key stages) %6.1f\n",
            run(g, 27, 10, st), run(g, 25, 10, st), run(g, 28, 10, st));
     for (int rep = 0; rep < 3; ++rep)
-        printf("  global:    asm %6.1f us   HIP (3 workgroups / CU) %6.1f   HIP (2 / CU) %6.1f\n", run(g, 0, 10, st), run(g, 9, 10, st), run(g, 10, 10, st));
+        printf("  global:    asm %6.1f us   HIP (LDS-DMA ring, 3 workgroups / CU) %6.1f   HIP (2 / CU) %6.1f   HIP without key loop %6.1f\n", run(g, 20, 10, st), run(g, 0, 10, st), run(g, 13, 10, st), run(g, 1, 10, st));
     return 0;
 }

@@ -272,6 +272,123 @@ void gemm_glds_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small-M layers (ViT-H / ViT-L at 256 px: M = 2048 rows, 56 - 480 tiles of 128 x 128): the two-stage kernel above spends 1.4 us per
+// k-tile against 0.5 us of MFMA, because its one-barrier-per-k-tile structure (__syncthreads = vmcnt(0)) keeps exactly ONE k-tile of
+// LDS-DMA in flight and nothing else is resident to cover the L2 / HBM latency.  Same tile, same fragment / MFMA body, same epilogue —
+// but an NST-stage ring with the DMA NST - 1 k-tiles ahead and COUNTED waits.  That is expressible in HIP because the compiler tracks
+// in-flight LDS-DMA per LDS object and models __builtin_amdgcn_s_waitcnt (see attn_global_kernel in attention.hip): every ring stage
+// is its own static __shared__ array, the DMA is issued in straight-line code (the tail re-fetches the last k-tile instead of
+// branching), the wait is the builtin.  buffer_load ... lds with the k-tile's scalar offset: no address arithmetic in the loop.
+// One workgroup per CU (NST x 32 KiB of LDS): made for layers whose tile count is below ~2 per CU anyway.
+// ---------------------------------------------------------------------------------------------------
+template <int NST>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
+    static_assert(NST == 3 || NST == 4, "ring depth");
+    constexpr int BM = 128, BN = 128, TILE = BM * BK * 2, STAGE = 2 * TILE;
+    __shared__ __attribute__((aligned(16))) char ring0[STAGE];
+    __shared__ __attribute__((aligned(16))) char ring1[STAGE];
+    __shared__ __attribute__((aligned(16))) char ring2[STAGE];
+    __shared__ __attribute__((aligned(16))) char ring3[NST == 4 ? STAGE : 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, zsplit = blockIdx.y;
+    const int kt0 = zsplit * (p.K / BK) / nsplit, nk = (zsplit + 1) * (p.K / BK) / nsplit;
+
+    // DMA piece i (0..3) of a wave covers rows i*32 + wave*8 .. +8 of the tile, 8 rows x 128 B = 1 KiB; swizzle on the source side
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    const int prow = lane >> 3, pc = lane & 7;
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 32 + wave * 8 + prow;
+        const int c = pc ^ ((r >> 1) & 7);
+        aoff[i] = (min(m0 + r, p.M - 1) * p.lda + c * 8) * 2;
+        woff[i] = ((n0 + r) * p.ldw + c * 8) * 2;
+    }
+#define SRH_RING_DMA(kt, ring) { const int so_ = (kt) * (BK * 2); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+        char* d_ = (ring) + (i * 32 + wave * 8) * 128; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)d_, 16, aoff[i], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(d_ + TILE), 16, woff[i], so_, 0, 0); } }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * 64) * 128, x_row0 = (wm * 64) * 128;
+    const int klast = nk - 1;
+
+    // prologue: k-tiles kt0 .. kt0 + NST - 2 into ring stages 0 .. NST - 2
+    SRH_RING_DMA(min(kt0, klast), ring0)
+    SRH_RING_DMA(min(kt0 + 1, klast), ring1)
+    if (NST == 4) SRH_RING_DMA(min(kt0 + 2, klast), ring2)
+    // one step = k-tile kt from ring stage `cur`; the DMA of k-tile kt + NST - 1 goes into stage `nxt` (k-tile kt - 1's: every wave is
+    // done with it once it has passed this step's barrier).  8 DMA per k-tile and wave: NST - 2 k-tiles may stay in flight at the wait.
+#define SRH_RING_STEP(kt, cur, nxt) { \
+        __builtin_amdgcn_s_waitcnt(NST == 4 ? 0x4F70 : 0x0F78);          /* vmcnt(16) / vmcnt(8) */ \
+        __builtin_amdgcn_s_barrier(); \
+        asm volatile("" ::: "memory"); \
+        SRH_RING_DMA(min((kt) + NST - 1, klast), nxt) \
+        if ((kt) < nk) { \
+            const char* sa = (cur) + x_row0; \
+            const char* sw = (cur) + TILE + w_row0; \
+            f16x8 fwA[2], fxA[2], fwB[2], fxB[2]; \
+            __builtin_amdgcn_sched_barrier(0); \
+            SRH_FRAG2(fwA, fxA, 0) \
+            SRH_FRAG2(fwB, fxB, 1) \
+            __builtin_amdgcn_sched_barrier(0); \
+            SRH_MMA2(fwA, fxA) \
+            __builtin_amdgcn_sched_barrier(0); \
+            SRH_FRAG2(fwA, fxA, 2) \
+            __builtin_amdgcn_sched_barrier(0); \
+            SRH_MMA2(fwB, fxB) \
+            __builtin_amdgcn_sched_barrier(0); \
+            SRH_FRAG2(fwB, fxB, 3) \
+            __builtin_amdgcn_sched_barrier(0); \
+            SRH_MMA2(fwA, fxA) \
+            SRH_MMA2(fwB, fxB) \
+            __builtin_amdgcn_sched_barrier(0); \
+        } }
+    for (int kt = kt0; kt < nk; kt += NST) {
+        if (NST == 4) {
+            SRH_RING_STEP(kt, ring0, ring3)
+            SRH_RING_STEP(kt + 1, ring1, ring0)
+            SRH_RING_STEP(kt + 2, ring2, ring1)
+            SRH_RING_STEP(kt + 3, ring3, ring2)
+        } else {
+            SRH_RING_STEP(kt, ring0, ring2)
+            SRH_RING_STEP(kt + 1, ring1, ring0)
+            SRH_RING_STEP(kt + 2, ring2, ring1)
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // the tail's redundant fetches have landed
+    __syncthreads();                         // every wave is done reading operand tiles: the ring becomes epilogue staging space
+    char* stage = wave == 0 ? ring0 : wave == 1 ? ring1 : wave == 2 ? ring2 : (NST == 4 ? ring3 : ring0 + 16384);
+    if (nsplit > 1) {  // raw f32 partial sums; bias / residual / activation are applied by splitk_reduce_kernel
+        GemmParams q = p;
+        q.bias = nullptr; q.resid = nullptr; q.pos = nullptr; q.act = 0; q.out_f16 = nullptr;
+        q.out_f32 = p.split_ws + (size_t)zsplit * p.M * p.N; q.ldc = p.N;
+        epilogue_staged<2, 0>(q, acc, stage, m0 + wm * 64, n0 + wn * 64, lane);
+        return;
+    }
+    epilogue_staged<2, 0>(p, acc, stage, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 128(M) x 160(N) x 64 LDS-DMA variant for the SMALL-M layers whose 128x128 tile count misses the chip's 512 workgroup slots
 // (two workgroups per CU): ViT-H at 256 px, B = 8 has M = 2048 rows, and fc1 (N = 5120) is 640 tiles of 128x128 = two rounds
 // with the second a quarter full, but exactly 512 tiles of 128x160 = ONE round.  Four waves stacked along M: wave tile 32(M) x 160(N) = 1 x 5 v_mfma_f32_32x32x16_f16 tiles (80
@@ -696,11 +813,27 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);
+    if (variant == 40 || variant == 41) {          // probe: the ring kernel, 4 / 3 stages, with the caller's split-K
+        const int sk = p.split_ws && p.splitk > 1 ? p.splitk : 1;
+        if (variant == 40) hipLaunchKernelGGL((gemm_ring_kernel<4>), dim3(grid, sk), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid, sk), dim3(256), 0, stream, p);
+        if (sk > 1) {
+            const size_t quads = (size_t)p.M * p.N / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (variant == 0 && p.split_ws && p.splitk > 1) {
         if (p.splitk != gemm_splitk_factor(p) || p.splitk > (p.K / BK)) return -2;
         hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid, p.splitk), dim3(256), 65536, stream, p);
         const size_t quads = (size_t)p.M * p.N / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    // at most one 128 x 128 tile per CU and a k-loop long enough to fill a ring: the three-stage ring kernel (one workgroup per CU, the
+    // L2 / HBM latency hidden by depth instead of by a second resident workgroup): ViT-H proj 21.3 -> 18.3 us (profiles/r04_gemm_ring_vith.txt)
+    if (variant == 0 && grid <= 256 && p.K / BK >= 12) {
+        hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid), dim3(256), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     if (variant == 11) hipLaunchKernelGGL((gemm_glds_kernel<1, 2>), dim3(grid), dim3(256), 65536, stream, p);

@@ -1,0 +1,84 @@
+"""The LDS-DMA rings written in HIP (gemm_ring_kernel, attn_global_kernel) rely on a compiler behaviour, not on a documented
+guarantee: with one static __shared__ array per ring stage and __builtin_amdgcn_s_waitcnt for the counted wait, hipcc adds NO
+s_waitcnt vmcnt(0) of its own in front of the LDS reads of the other stages.  If a toolchain update changes that, the
+kernels stay correct but silently lose their overlap — so the generated ISA is checked here: inside the ring loops the only vmcnt
+waits are the ones the source asks for.  CPU only (hipcc -S cross-compiles for gfx950)."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")) if c and os.path.exists(c)), None)
+pytestmark = pytest.mark.skipif(HIPCC is None, reason="hipcc not found")
+
+
+def _isa(src, extra=()):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *extra,
+               os.path.join(ROOT, "sam_road_amd", "csrc", src), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(out).read()
+
+
+def _kernel_body(isa, mangled_fragment):
+    m = re.search(r"^(_Z\w*" + re.escape(mangled_fragment) + r"\w*):", isa, re.M)
+    assert m, f"kernel {mangled_fragment} not found"
+    a = m.start()
+    return isa[a:isa.index(".Lfunc_end", a)]
+
+
+def _events(body):
+    ev = []
+    for ln in body.split("\n"):
+        t = ln.split(";")[0].strip()
+        if t.startswith("s_barrier"):
+            ev.append("B")
+        elif re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t):
+            ev.append(int(re.search(r"vmcnt\((\d+)\)", t).group(1)))
+        elif re.match(r"(buffer_load\w* .* lds|global_load_lds)", t):
+            ev.append("D")
+        elif t.startswith("ds_read"):
+            ev.append("R")
+    return ev
+
+
+def test_gemm_ring_loop_has_only_the_counted_wait():
+    body = _kernel_body(_isa("gemm.hip"), "gemm_ring_kernelILi3E")
+    ev = _events(body)
+    # the loop: [vmcnt(8), barrier, 8 DMA, fragment reads] x 3 per trip; find the three steps by their counted wait
+    idx = [i for i, e in enumerate(ev) if e == 8]
+    assert len(idx) >= 3, ev[:80]
+    for i in idx[:3]:
+        assert ev[i + 1] == "B", ev[i:i + 4]
+        step = []
+        for e in ev[i + 2:]:                        # the step's DMA issue and fragment reads: up to the last read before the next barrier / wait-then-barrier
+            if e == "B" or (isinstance(e, int) and len([x for x in step if x == "R"]) >= 16):
+                break
+            step.append(e)
+        assert step.count("D") == 8 and step.count("R") >= 16, step
+        assert not [e for e in step if isinstance(e, int)], f"compiler-inserted vmcnt wait inside a ring step: {step}"
+
+
+def test_global_attention_ring_has_one_wait_per_stage():
+    body = _kernel_body(_isa("attention.hip", ["-fno-honor-nans"]), "attn_global_kernelILi32ELi3E")
+    ev = _events(body)
+    # after the prologue every stage is: vmcnt(0) (ours), barrier, rel_h read, 4 DMA, K / V fragment reads — and nothing else that waits
+    stages = 0
+    for i, e in enumerate(ev):
+        if e == "B" and ev[i + 1:i + 6].count("D") == 4:
+            nxt = ev[i + 1:]
+            upto = nxt.index("B") if "B" in nxt else len(nxt)
+            waits = [x for x in nxt[:upto] if isinstance(x, int)]
+            assert nxt[:upto].count("R") >= 8, nxt[:upto]
+            if upto < len(nxt):                     # a following stage exists: exactly its own hand-over wait, at the end
+                assert waits == [0], f"stage carries waits {waits}: {nxt[:upto]}"
+                after_reads = nxt[:upto][::-1].index("R")
+                assert nxt[:upto][len(nxt[:upto]) - after_reads:] == [0] or 0 in nxt[:upto][-after_reads - 1:], nxt[:upto]
+            stages += 1
+    assert stages >= 2, ev

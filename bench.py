@@ -38,6 +38,135 @@ GFLOP_PER_TILE = 196.18          # algorithmic, ViT-B 512^2 en
 MFMA_PEAK_TFLOPS = 2500.0        # MI355X dense f16/bf16 (MI355X_MICROARCH.md)
 
 
+WORKLOADS = {
+    "encdec": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE, yaml="toponet_vitb_512_cityscale.yaml",
+                   what="ViT-B encoder + map_decoder (BASELINE configs[1])"),
+    "full": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE + 2.8, yaml="toponet_vitb_512_cityscale.yaml",
+                 what="full SAMRoad.forward: encoder + map_decoder + sampler + TopoNet on 256 points / tile (BASELINE configs[2])"),
+    "vith256": dict(version="vit_h", patch=256, batch=8, gflop=332.23 + 0.21, yaml="toponet_vith_256.yaml",
+                    what="ViT-H encoder + map_decoder (BASELINE configs[4])"),
+}
+
+
+def build_workload(name, batch, rank, dev, distributed, net=None, sd=None):
+    """The model, seeded random weights and resident synthetic inputs of one BASELINE workload; returns (net, state_dict, cfg, step, B, P, WL)
+    where step() is one pass of the hot path over one batch.  `net` / `sd`: reuse an already built model of the same architecture."""
+    from sam_road_amd import Config, SAMRoad
+    WL = WORKLOADS[name]
+    P = WL["patch"]
+    cfg = Config(SAM_VERSION=WL["version"], PATCH_SIZE=P, TOPONET_VERSION="normal", SAM_CKPT_PATH="",
+                 NO_SAM=False, USE_SAM_DECODER=False, ENCODER_LORA=False, NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16)
+    if net is None:
+        net = SAMRoad(cfg)
+        # seeded random-init weights of the named architecture (no checkpoint exists offline)
+        g = torch.Generator().manual_seed(1234)
+        sd = {}
+        for k, v in net.state_dict().items():
+            if rank == 0:
+                if v.dim() == 1 and k.endswith("weight"):
+                    t = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+                else:
+                    t = 0.02 * torch.randn(v.shape, generator=g)
+            else:
+                t = torch.empty(v.shape)
+            sd[k] = t
+        if rank == 0:
+            net.load_state_dict(sd, strict=True)
+        net.eval().to(dev)
+        if distributed:
+            # rank 0 packs the weights once; the PACKED fp16 arena (~175 MB for ViT-B) goes to the other ranks device-to-device in
+            # one RCCL broadcast over xGMI (SAMRoad.share_packed_weights) — before the timed region
+            net.share_packed_weights(src=0)
+
+    B = batch or WL["batch"]
+    gi = torch.Generator().manual_seed(100 + rank)
+    rgb = (torch.rand((B, P, P, 3), generator=gi) * 255).round().to(dev)
+    step = lambda: net.infer_masks_and_img_features(rgb)
+    if name == "full":
+        # 256 synthetic graph points per tile (integer pixels, >= 16 px apart like NMS output), pairs by the pass-2 query
+        # builder (kNN 16 within 64 px, inferencer.py:148-176)
+        import numpy as np
+        from sam_road_amd.inferencer import build_patch_queries, _collate
+        rng = np.random.default_rng(7 + rank)
+        qs = []
+        for _ in range(B):
+            cand = rng.integers(0, P // 16, size=(4096, 2))
+            _, first = np.unique(cand[:, 0] * 64 + cand[:, 1], return_index=True)
+            pts = (cand[np.sort(first)][:256] * 16 + rng.integers(0, 4, size=(256, 2))).astype(np.int64)
+            qs.append(build_patch_queries(pts, 0, 0, P, P, cfg))
+        pts_t = torch.as_tensor(_collate([q[1] for q in qs])).to(dev)
+        pairs_t = torch.as_tensor(_collate([q[2] for q in qs])).to(dev)
+        valid_t = torch.as_tensor(_collate([q[3] for q in qs])).to(dev)
+        step = lambda: net(rgb, pts_t, pairs_t, valid_t)[1::2]
+    step.rgb = rgb
+    return net, sd, cfg, step, B, P, WL
+
+
+def instrumented_rows(ctx, step, dev, nrep):
+    """Per-class GPU time of `nrep` steps: HIP events around every launch on the launch stream (srh_profile_*), first step discarded."""
+    ctx.profile_enable(True)
+    step()                                      # first instrumented step creates the event pool: discarded
+    ctx.profile_read()
+    torch.cuda.synchronize(dev)
+    t_i = time.perf_counter()
+    for _ in range(nrep):
+        step()
+    torch.cuda.synchronize(dev)
+    instrumented_ms = 1e3 * (time.perf_counter() - t_i) / nrep
+    rows = ctx.profile_read()
+    ctx.profile_enable(False)
+    return rows, instrumented_ms
+
+
+def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b):
+    """BASELINE configs[2] (`full`) and configs[4] (`vith256`) beside the headline, bounded (a few seconds each): the same warm-up /
+    barrier / max-over-ranks timing as the headline's timed region, plus rank 0's all-GEMM roofline fraction from an instrumented pass."""
+    import torch.distributed as dist
+    from sam_road_amd import _lib
+    res = {}
+    for name, steps in (("full", 20), ("vith256", 20)):
+        reuse = name == "full"                  # configs[2] is the headline's model with the TopoNet branch switched on
+        net, _, _, step, B, P, WL = build_workload(name, 0, rank, dev, distributed, net=net_b if reuse else None, sd=sd_b if reuse else None)
+
+        def sync_all():
+            torch.cuda.synchronize(dev)
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+        for _ in range(3):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = step()
+        sync_all()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        assert all(torch.isfinite(x).all() for x in o)
+        tps = world * B * steps / el
+        r = {"config": f"{WL['yaml']}, batch={B} {P}x{P} tiles per GPU, {WL['what']}", "tiles_per_s": round(tps, 2),
+             "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": 3, "n_gpus": world, "dtype": "f16",
+             "gflop_per_tile_algorithmic": WL["gflop"],
+             "whole_path_mfma_frac": round(tps / world * WL["gflop"] / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+        if rank == 0:
+            ctx = _lib.Context.get(local_rank)
+            rows, _ = instrumented_rows(ctx, step, dev, 3)
+            gemm = [x for x in rows if x["name"].startswith("gemm_")]
+            fl, ms, n = sum(x["flops"] for x in gemm), sum(x["ms"] for x in gemm), sum(x["launches"] for x in gemm)
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            r["gemm"] = {"achieved_tflops": round(ach, 2), "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "launches_per_step": n // 3,
+                         "avg_launch_ms": round(ms / max(n, 1), 5)}
+            r["by_class_ms_per_step"] = {x["name"]: round(x["ms"] / 3, 4) for x in rows}
+        res[name] = r
+        if not reuse:
+            del net, step
+            torch.cuda.empty_cache()
+    return res
+
+
 def scene_block(args, net, sd, dev, rank, world, distributed):
     """BASELINE configs[3]: ms per synthetic 2048 x 2048 CityScale scene (toponet_vitb_512_cityscale.yaml tiling: 256 tiles of
     512^2, INFER_BATCH_SIZE 64) through the CLI's scene loop — end to end to the edge list.  N = 1: the one-GPU pipeline
@@ -149,6 +278,19 @@ def plumbing_cpu(args):
         dist.destroy_process_group()
 
 
+def _respawn_under_launcher(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-exec the same command line under
+    torch.distributed.run (one rank per GPU), so that a bare invocation can never print a one-rank number as the N-GPU point."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +307,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="tuning aid: skip the finite-output check (kernel ablations)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 3 s sustained leg (sustained_tiles_per_s, SMI clock)")
     ap.add_argument("--no-scene", action="store_true", help="skip the scene block (ms per 2048^2 CityScale scene; tile-sharded over the ranks when N > 1)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the bounded `workloads` block (BASELINE configs[2] full SAMRoad.forward and configs[4] ViT-H 256^2 beside the headline)")
     ap.add_argument("--scenes", type=int, default=16, help="scenes of the scene block's timed stream")
     ap.add_argument("--scene-timeout", type=float, default=240.0, help="deadline of the scene block in seconds (the line is printed without it afterwards)")
     ap.add_argument("--plumbing-cpu", action="store_true",
@@ -172,6 +315,11 @@ def main():
                          "oracle stand-in model (tests/test_distributed_cpu.py) — checks env handling, collectives and the JSON line without a GPU")
     args = ap.parse_args()
     warnings.simplefilter("ignore")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_respawn_under_launcher(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} rank(s); launch with\n"
+                 f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
     if args.plumbing_cpu:
         return plumbing_cpu(args)
 
@@ -191,59 +339,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from sam_road_amd import Config, SAMRoad
     from sam_road_amd import _lib
 
-    WL = {"encdec": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE, yaml="toponet_vitb_512_cityscale.yaml",
-                         what="ViT-B encoder + map_decoder (BASELINE configs[1])"),
-          "full": dict(version="vit_b", patch=512, batch=16, gflop=GFLOP_PER_TILE + 2.8, yaml="toponet_vitb_512_cityscale.yaml",
-                       what="full SAMRoad.forward: encoder + map_decoder + sampler + TopoNet on 256 points / tile (BASELINE configs[2])"),
-          "vith256": dict(version="vit_h", patch=256, batch=8, gflop=332.23 + 0.21, yaml="toponet_vith_256.yaml",
-                          what="ViT-H encoder + map_decoder (BASELINE configs[4])")}[args.workload]
-    P = WL["patch"]
-    cfg = Config(SAM_VERSION=WL["version"], PATCH_SIZE=P, TOPONET_VERSION="normal", SAM_CKPT_PATH="",
-                 NO_SAM=False, USE_SAM_DECODER=False, ENCODER_LORA=False, NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16)
-    net = SAMRoad(cfg)
-    # seeded random-init weights of the named architecture (no checkpoint exists offline)
-    g = torch.Generator().manual_seed(1234)
-    sd = {}
-    for k, v in net.state_dict().items():
-        if rank == 0:
-            if v.dim() == 1 and k.endswith("weight"):
-                t = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
-            else:
-                t = 0.02 * torch.randn(v.shape, generator=g)
-        else:
-            t = torch.empty(v.shape)
-        sd[k] = t
-    if rank == 0:
-        net.load_state_dict(sd, strict=True)
-    net.eval().to(dev)
+    rccl_ranks = 1
     if distributed:
-        # rank 0 packs the weights once; the PACKED fp16 arena (~175 MB for ViT-B) goes to the other ranks device-to-device in
-        # one RCCL broadcast over xGMI (SAMRoad.share_packed_weights) — before the timed region
-        net.share_packed_weights(src=0)
+        # the number of ranks the collective library actually connected (an on-device all-reduce of ones): the line is only printed
+        # as an N-GPU line when this equals N
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        rccl_ranks = int(t.item())
+        assert rccl_ranks == world == args.gpus, f"--gpus {args.gpus}, WORLD_SIZE {world}, but the collective spans {rccl_ranks} rank(s)"
 
-    B = args.batch or WL["batch"]
-    gi = torch.Generator().manual_seed(100 + rank)
-    rgb = (torch.rand((B, P, P, 3), generator=gi) * 255).round().to(dev)
-    step = lambda: net.infer_masks_and_img_features(rgb)
-    if args.workload == "full":
-        # 256 synthetic graph points per tile (integer pixels, >= 16 px apart like NMS output), pairs by the pass-2 query
-        # builder (kNN 16 within 64 px, inferencer.py:148-176)
-        import numpy as np
-        from sam_road_amd.inferencer import build_patch_queries, _collate
-        rng = np.random.default_rng(7 + rank)
-        qs = []
-        for _ in range(B):
-            cand = rng.integers(0, P // 16, size=(4096, 2))
-            _, first = np.unique(cand[:, 0] * 64 + cand[:, 1], return_index=True)
-            pts = (cand[np.sort(first)][:256] * 16 + rng.integers(0, 4, size=(256, 2))).astype(np.int64)
-            qs.append(build_patch_queries(pts, 0, 0, P, P, cfg))
-        pts_t = torch.as_tensor(_collate([q[1] for q in qs])).to(dev)
-        pairs_t = torch.as_tensor(_collate([q[2] for q in qs])).to(dev)
-        valid_t = torch.as_tensor(_collate([q[3] for q in qs])).to(dev)
-        step = lambda: net(rgb, pts_t, pairs_t, valid_t)[1::2]
+    net, sd, cfg, step, B, P, WL = build_workload(args.workload, args.batch, rank, dev, distributed)
+    rgb = step.rgb
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -310,7 +418,7 @@ def main():
                   else f"tiles/sec ({P}x{P} {WL['version']}, {WL['what']})",
         "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "config": {"workload": f"{WL['yaml']}, batch={B} {P}x{P} tiles per GPU, {WL['what']}",
                    "tiles_per_step_per_gpu": B, "patch": P, "input": "f32 NHWC resident in HBM",
                    "weights": "seeded random init", "parallelism": f"tile-dp{world}",
@@ -338,17 +446,7 @@ def main():
         # the packet handling would remove; `achieved_if_overhead_subtracted` shows the effect on the GEMM figure.
         ovh = ctx.profile_overhead(stream)
         nrep = max(1, min(args.steps, 5))
-        ctx.profile_enable(True)
-        step()                                      # first instrumented step creates the event pool: discarded
-        ctx.profile_read()
-        torch.cuda.synchronize(dev)
-        t_i = time.perf_counter()
-        for _ in range(nrep):
-            step()
-        torch.cuda.synchronize(dev)
-        instrumented_ms = 1e3 * (time.perf_counter() - t_i) / nrep
-        rows = ctx.profile_read()
-        ctx.profile_enable(False)
+        rows, instrumented_ms = instrumented_rows(ctx, step, dev, nrep)
 
         def agg(sel):
             fl, ms, n = sum(r["flops"] for r in sel), sum(r["ms"] for r in sel), sum(r["launches"] for r in sel)
@@ -463,6 +561,12 @@ def main():
         # BASELINE.md §5 records this leg as the baseline number of the >= 4x target (no number is published by the reference)
         out["vs_baseline"] = round(tiles_per_s / legs["fp32_eager"], 3)
         out["vs_baseline_def"] = "value / reference_gpu.fp32_eager (reference PyTorch path on the same MI355X, BASELINE.md §3 C2(ii), §5)"
+
+    if not args.no_workloads and args.workload == "encdec" and not args.batch:
+        # BASELINE configs[2] and configs[4] beside the headline, so that the driver's own run of the default command times them
+        wl = side_workloads(args, dev, rank, local_rank, world, distributed, net, sd)
+        if rank == 0:
+            out["workloads"] = wl
 
     if not args.no_scene and args.workload == "encdec":
         # The scene block must never cost the tiles/s line.  On N > 1 its exchange steps (banded point-to-point canvas reduce, point

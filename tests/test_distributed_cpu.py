@@ -396,23 +396,32 @@ def test_pipelined_tile_sharded_scenes_world8_match_single_process():
 def test_bench_launch_contract_two_ranks_on_cpu():
     """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --plumbing-cpu`: the driver's multi-GPU launch
     line on gloo / CPU with the oracle stand-in — rank / world / master address from the environment, collectives connect both
-    ranks, rank 0 prints ONE JSON line; the tile-sharded scenes equal the one-process run."""
+    ranks, rank 0 prints ONE JSON line; the tile-sharded scenes equal the one-process run.  The BARE form `python bench.py --gpus 2
+    ...` (no launcher environment) re-execs itself under the launcher and prints the same 2-rank line — it can never report a
+    one-rank run as the 2-GPU point; a launcher whose WORLD_SIZE contradicts --gpus is refused."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
     lines = {}
-    for n in (1, 2):
+    for form, n in (("plain", 1), ("launcher", 2), ("bare", 2)):
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--plumbing-cpu"]
-        if n > 1:
+        if form == "launcher":
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port())] + cmd[1:]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         js = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(js) == 1, r.stdout
-        lines[n] = js[0]
-    assert lines[2]["collective_ranks"] == 2 and lines[2]["n_gpus"] == 2 and lines[2]["plumbing_only"] and lines[2]["value"] is None
-    assert lines[1]["graph_points"] == lines[2]["graph_points"] and lines[1]["edges"] == lines[2]["edges"]
-    assert len(lines[2]["per_rank"]) == 2 and lines[2]["per_rank"][1][1] > 0        # rank 1 shipped canvas bytes
+        lines[form] = js[0]
+    for form in ("launcher", "bare"):
+        two = lines[form]
+        assert two["collective_ranks"] == 2 and two["n_gpus"] == 2 and two["plumbing_only"] and two["value"] is None
+        assert lines["plain"]["graph_points"] == two["graph_points"] and lines["plain"]["edges"] == two["edges"]
+        assert len(two["per_rank"]) == 2 and two["per_rank"][1][1] > 0        # rank 1 shipped canvas bytes
+    # a launcher environment that contradicts --gpus: refused with the launch line, nothing printed as a result
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--plumbing-cpu"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)
+    assert r.returncode != 0 and "torch.distributed.run" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 5
+#define SRH_ABI_VERSION 6
 
 typedef enum {
     SRH_OK = 0,
@@ -128,6 +128,19 @@ int srh_scene_normalise(srh_ctx* ctx, const float* canvas_kp, const float* canva
 /* out = act(A[M,K] W[N,K]^T + bias) (+resid); A,W fp16; N%128==0, K%64==0. act: 0/1 GELU/2 ReLU. */
 int srh_op_gemm(srh_ctx* ctx, const void* A_f16, const void* W_f16, const float* bias, const float* resid,
                 int M, int N, int K, int act, float* out_f32, void* out_f16, void* stream);
+/* The same with the operand layouts the model uses between fc1 and fc2 of a ViT block (reference model.py:245-258 through the SAM
+ * fork's MLPBlock: lin2(act(lin1(x)))): the MLP's hidden activation is kept in the BLOCKED-16 layout — 1 KiB blocks of 32 rows x 16
+ * columns, element (m, n) at fp16 index ((m/32)*(cols/16) + n/16)*512 + ((n%16)/8)*256 + (m%32)*8 + n%8.  flags: SRH_GEMM_A_BLOCKED16
+ * = A_f16 is in that layout, SRH_GEMM_OUT_BLOCKED16 = out_f16 is written in it.  Only the persistent 256x192 kernel understands the
+ * layout: M % 256 == 0, N % 192 == 0, K % 768 == 0, >= 128 tiles, a bias, fp16 output only, (A blocked, act 0) or (out blocked, act 1
+ * GELU); anything else returns SRH_ERR_UNSUPPORTED.  flags == 0 is srh_op_gemm. */
+#define SRH_GEMM_A_BLOCKED16 1
+#define SRH_GEMM_OUT_BLOCKED16 2
+int srh_op_gemm_ex(srh_ctx* ctx, const void* A_f16, const void* W_f16, const float* bias, const float* resid,
+                   int M, int N, int K, int act, float* out_f32, void* out_f16, int flags, void* stream);
+/* Device bytes the context owns right now (activation / scene / TopoNet workspaces, the GEMM tile-table slab): grows only when a larger
+ * batch is first seen, flat in steady state — what tests/test_gpu_ops.py::test_ctx_memory_is_flat_over_batch_sizes watches. */
+size_t srh_ctx_device_bytes(const srh_ctx* ctx);
 /* 3x3 pad-1 conv over channels-last [B,S,S,C] as implicit GEMM; W_f16 [N, 9*C] (k = tap*C + c). */
 int srh_op_conv3x3(srh_ctx* ctx, const void* A_f16, const void* W_f16, int B, int S, int C, int N,
                    float* out_f32, void* stream);

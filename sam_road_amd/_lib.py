@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRH_LIB_PATH") or os.path.join(_HERE, "libsamroad_hip.so")
 
 SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
+SRH_GEMM_A_BLOCKED16, SRH_GEMM_OUT_BLOCKED16 = 1, 2       # srh_op_gemm_ex flags (include/samroad_hip.h)
 
 
 class SrhError(RuntimeError):
@@ -51,6 +52,8 @@ SYMBOLS = {
     "srh_scene_pass1": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "srh_scene_normalise": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "srh_op_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "srh_op_gemm_ex": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "srh_ctx_device_bytes": (C.c_size_t, [_P]),
     "srh_op_conv3x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "srh_op_layernorm": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "srh_op_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsamroad_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_q192.hip", "gemm_z192.hip", "norm.hip", "patch.hip", "attention.hip", "attention_hdx.hip", "decoder.hip", "sam_decoder.hip", "topo.hip", "topo_fused.hip", "host_geom.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_z192.hip", "norm.hip", "patch.hip", "attention.hip", "attention_hdx.hip", "decoder.hip", "sam_decoder.hip", "topo.hip", "topo_fused.hip", "host_geom.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 # The softmax row maxima are taken over MFMA results; without this flag every fmaxf operand gets a v_max x, x to quiet a

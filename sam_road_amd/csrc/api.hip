@@ -45,6 +45,7 @@ struct srh_ctx {
     // encoder / decoder workspace
     DevBuf a0, x, xn16, delta16, delta16b, qkv16, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16;
     DevBuf scores_ws, emb_ws, counter, split_ws;
+    ZTileTables ztab;            // gemm_z192's tile-order tables (one bounded slab, freed with the context)
     // SAM MaskDecoder branch workspace
     DevBuf sd_keys, sd_keys16, sd_k16, sd_v16, sd_a16, sd_u0, sd_u0_16, sd_u1_16, sd_low, sd_tok;
     // toponet workspace
@@ -132,6 +133,7 @@ static int run(srh_ctx* c, const char* cls, double flops, double bytes, hipStrea
 
 static int gemm(srh_ctx* c, const char* cls, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
+    p.ztab = &c->ztab;
     const int sk = gemm_splitk_factor(p);
     if (sk > 1) {       // small-M layers (ViT-L / ViT-H at 256 px): deterministic split-K through a ctx-owned f32 workspace
         if (c->split_ws.ensure((size_t)sk * p.M * p.N * 4)) return fail(c, SRH_ERR_HIP, "split-K workspace allocation failed");
@@ -175,8 +177,20 @@ extern "C" void srh_ctx_destroy(srh_ctx* c) {
                       &c->sd_low, &c->sd_tok,
                       &c->t_feat16, &c->t_pf16, &c->t_pair16};
     for (DevBuf* b : bufs) b->release();
+    c->ztab.release();
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     delete c;
+}
+
+extern "C" size_t srh_ctx_device_bytes(const srh_ctx* c) {
+    if (!c) return 0;
+    const DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->delta16, &c->delta16b, &c->qkv16, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
+                            &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
+                            &c->sd_keys, &c->sd_keys16, &c->sd_k16, &c->sd_v16, &c->sd_a16, &c->sd_u0, &c->sd_u0_16, &c->sd_u1_16,
+                            &c->sd_low, &c->sd_tok, &c->t_feat16, &c->t_pf16, &c->t_pair16};
+    size_t n = c->ztab.device_bytes();
+    for (const DevBuf* b : bufs) n += b->cap;
+    return n;
 }
 
 extern "C" const char* srh_last_error(const srh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
@@ -717,12 +731,11 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         g.bias = w->patch_b; g.pos = w->pos; g.pos_rows = S * S; g.out_f32 = c->x.as<float>(); g.ldc = D;
         TRY(gemm(c, "gemm_patch_embed", g, s));
     }
-    // Residual stream: x stays fp32.  Where the persistent q192 GEMM applies (gemm_q192.hip: fp16 output only), proj / fc2
+    // Residual stream: x stays fp32.  Where the persistent z192 GEMM applies (gemm_z192.hip: fp16 output only), proj / fc2
     // write their branch output (bias included) as fp16 into delta16 and the NEXT LayerNorm pass folds "x += delta" into
     // its read of x — the same HBM bytes as the GEMM-epilogue residual add, but moved out of the GEMM's exposed epilogue
     // into a streaming kernel.  Otherwise the GEMM epilogue adds the residual itself.
-    const bool use_q192 = true;
-    // When BOTH branch GEMMs of a block go through q192, the attention branch (delta16) is not written back to x by the second
+    // When BOTH branch GEMMs of a block go through z192, the attention branch (delta16) is not written back to x by the second
     // LayerNorm — it only normalises x + delta16 — and the next block's first LayerNorm folds both branches, (x + delta16) +
     // delta16b, and writes x once per block: 275 instead of 300 MB of LayerNorm traffic per block at B = 16, same sums in the
     // same order bit for bit.
@@ -731,19 +744,19 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         GemmParams gq;
         gq.A = A; gq.lda = lda; gq.W = W; gq.ldw = K; gq.M = T; gq.N = D; gq.K = K; gq.bias = bias; gq.a_blocked16 = a_blocked;
         gq.out_f16 = second ? c->delta16b.as<f16>() : c->delta16.as<f16>(); gq.ldc16 = D;
-        if (use_q192 && q192_preferred(gq)) { (second ? pend_b : pend_a) = true; return gemm(c, cls, gq, s); }
+        if (z192_preferred(gq)) { (second ? pend_b : pend_a) = true; return gemm(c, cls, gq, s); }
         GemmParams gp = gq;
         gp.out_f16 = nullptr; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
         return gemm(c, cls, gp, s);
     };
-    bool defer_x = false;                                 // both branch GEMMs of the blocks take q192 (same shapes in every block)
+    bool defer_x = false;                                 // both branch GEMMs of the blocks take z192 (same shapes in every block)
     {
         GemmParams gq;
         gq.M = T; gq.N = D; gq.K = D; gq.lda = D; gq.ldw = D; gq.ldc16 = D; gq.out_f16 = c->delta16.as<f16>();
         gq.A = c->attn16.as<f16>(); gq.W = w->blocks.empty() ? nullptr : w->blocks[0].proj_w; gq.bias = w->blocks.empty() ? nullptr : w->blocks[0].proj_b;
         GemmParams g2 = gq;
         g2.K = 4 * D; g2.lda = 4 * D; g2.ldw = 4 * D;
-        defer_x = use_q192 && !w->blocks.empty() && q192_preferred(gq) && q192_preferred(g2);
+        defer_x = !w->blocks.empty() && z192_preferred(gq) && z192_preferred(g2);
     }
     // a LayerNorm pass over x (+ pending branches).  write_x: fold the pending branches into x for good.
     auto block_ln = [&](const float* gamma, const float* beta, bool write_x) -> int {
@@ -785,7 +798,7 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
             t1.out_blocked16 = 1;
             t2.A = c->hid16.as<f16>(); t2.lda = 4 * D; t2.W = b.fc2_w; t2.ldw = 4 * D; t2.M = T; t2.N = D; t2.K = 4 * D; t2.bias = b.fc2_b;
             t2.out_f16 = c->delta16b.as<f16>(); t2.ldc16 = D; t2.a_blocked16 = 1;
-            hid_blocked = q192_preferred(g1) && z192_supported(t1) && q192_preferred(t2) && z192_supported(t2);
+            hid_blocked = z192_preferred(t1) && z192_preferred(t2);
         }
         g1.out_blocked16 = hid_blocked;
         TRY(gemm(c, "gemm_fc1", g1, s));
@@ -936,15 +949,22 @@ extern "C" int srh_scene_normalise(srh_ctx* c, const float* canvas_kp, const flo
 }
 
 // ---- op level ------------------------------------------------------------------------------------------------
-extern "C" int srh_op_gemm(srh_ctx* c, const void* A, const void* W, const float* bias, const float* resid, int M,
-                           int N, int K, int act, float* out_f32, void* out_f16, void* stream) {
+extern "C" int srh_op_gemm_ex(srh_ctx* c, const void* A, const void* W, const float* bias, const float* resid, int M,
+                              int N, int K, int act, float* out_f32, void* out_f16, int flags, void* stream) {
     if (!c || !A || !W) return fail(c, SRH_ERR_BAD_ARG, "srh_op_gemm: null argument");
+    if (flags & ~(SRH_GEMM_A_BLOCKED16 | SRH_GEMM_OUT_BLOCKED16)) return fail(c, SRH_ERR_BAD_ARG, "srh_op_gemm_ex: unknown flag");
     hipSetDevice(c->device);
     GemmParams g;
     g.A = (const f16*)A; g.lda = K; g.W = (const f16*)W; g.ldw = K; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.resid = resid; g.ldr = N; g.act = act;
     g.out_f32 = out_f32; g.ldc = N; g.out_f16 = (f16*)out_f16; g.ldc16 = N;
+    g.a_blocked16 = (flags & SRH_GEMM_A_BLOCKED16) != 0; g.out_blocked16 = (flags & SRH_GEMM_OUT_BLOCKED16) != 0;
     return gemm(c, "gemm_op", g, (hipStream_t)stream);
+}
+
+extern "C" int srh_op_gemm(srh_ctx* c, const void* A, const void* W, const float* bias, const float* resid, int M,
+                           int N, int K, int act, float* out_f32, void* out_f16, void* stream) {
+    return srh_op_gemm_ex(c, A, W, bias, resid, M, N, K, act, out_f32, out_f16, 0, stream);
 }
 
 extern "C" int srh_op_conv3x3(srh_ctx* c, const void* A, const void* W, int B, int S, int C, int N, float* out_f32,

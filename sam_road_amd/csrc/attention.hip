@@ -732,16 +732,6 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     }
 }
 
-// hipFuncSetAttribute is per device: once per (kernel group, device) of the process
-static bool first_use_on_device(unsigned& mask) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned bit = 1u << (dev & 31);
-    if (mask & bit) return false;
-    mask |= bit;
-    return true;
-}
-
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
 #ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): ablation switches change the RESULT
@@ -757,11 +747,12 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
         const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
         const int lds = (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 6 + 256 * 2 * p.win * 4;
         if (lds > 160 * 1024) return -2;
-        static unsigned gattr = 0;
-        if (first_use_on_device(gattr)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        static OncePerDevice generic_opt_in;
+        if (!generic_opt_in.run([] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            }))
+            return -3;
         const dim3 grid(p.B * nw * nw * p.heads * nqb);
         if (p.hd == 64) hipLaunchKernelGGL(attn_generic_kernel<8>, grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL(attn_generic_kernel<10>, grid, dim3(256), lds, s, p);
@@ -777,9 +768,9 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
         else if (p.S == 16) hipLaunchKernelGGL((attn_global_kernel<16, 2>), dim3(grid), dim3(256), 0, s, p);
         else return -2;
     } else if (p.win == 14) {
-        static unsigned wattr = 0;
-        if (first_use_on_device(wattr))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        static OncePerDevice window_opt_in;
+        if (!window_opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS) == hipSuccess; }))
+            return -3;
         const int nw = (p.S + 13) / 14;
         hipLaunchKernelGGL(attn_window_kernel, dim3(p.B * nw * nw * p.heads), dim3(256), WIN_LDS, s, p);
     } else {

@@ -321,13 +321,9 @@ template <int HD, int WIN>
 int hdx_launch(const AttnParams& p, hipStream_t s) {
     constexpr int NDT = (HD + 31) / 32, NT = GeomX<WIN>::NT;
     constexpr int lds = NT * 32 * HD * 2 + NT * HD * 64 + (32 * NDT - HD) * 64 + 4 * 32 * (WIN + 1) * 4;   // WIN 14: 78.5 KiB = two per CU
-    static unsigned attr = 0;                                     // per device of the process (the attribute is per device)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!(attr & (1u << (dev & 31)))) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_hdx_kernel<HD, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr |= 1u << (dev & 31);
-    }
+    static OncePerDevice opt_in;                                  // per template instantiation; the attribute is per device
+    if (!opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_hdx_kernel<HD, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }))
+        return -3;
     const int nw = WIN == 14 ? (p.S + WIN - 1) / WIN : 1;
     const int grid = p.B * p.heads * nw * nw;
     hipLaunchKernelGGL((attn_hdx_kernel<HD, WIN>), dim3(grid), dim3(256), lds, s, p);

@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
+#include <utility>
 
 namespace srh {
 
@@ -697,12 +698,10 @@ template <int AMODE, int WN, int WM, int TN, int TM>
 static int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32, THREADS = WN * WM * 64;
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    static bool attr_set = false;
     auto kern = gemm_kernel<AMODE, WN, WM, TN, TM>;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static OncePerDevice opt_in;       // one per template instantiation
+    if (!opt_in.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess; }))
+        return -3;
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -712,10 +711,6 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // (ViT-H fc1 at M = 2048: 640 -> 512 workgroups on 512 slots; measured 46.0 -> 41.3 us).  Not for the few-tile layers: proj / fc2 of
 // ViT-H as 128 tiles x split-K 4 measured no better than 128x128 tiles without / with split-K 3 (profiles/r03_vith_gemm_t160.txt).
 static bool use_tile160(const GemmParams& p) {
-#ifdef SRH_TUNING      // probe builds: A/B switch
-    static const bool on = !(getenv("SRH_GEMM_T160") && atoi(getenv("SRH_GEMM_T160")) == 0);
-    if (!on) return false;
-#endif
     if (p.conv_S > 0 || p.pos || p.N % 160 != 0 || p.N % 128 != 0 || p.K % BK != 0 || p.M >= 4096) return false;
     const long t128 = (long)((p.M + 127) / 128) * (p.N / 128), t160 = (long)((p.M + 127) / 128) * (p.N / 160);
     return t128 > 512 && t160 <= 512;
@@ -723,12 +718,8 @@ static bool use_tile160(const GemmParams& p) {
 
 // Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
 int gemm_splitk_factor(const GemmParams& p) {
-#ifdef SRH_TUNING      // probe builds: A/B switch
-    static const bool on = !(getenv("SRH_GEMM_SPLITK") && atoi(getenv("SRH_GEMM_SPLITK")) == 0);
-    if (!on) return 1;
-#endif
     if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
-    if (p.M >= 4096 || q192_preferred(p)) return 1;
+    if (p.M >= 4096 || z192_preferred(p)) return 1;
     if (use_tile160(p)) return 1;
     const long tiles = (long)(p.M / 128) * (p.N / 128);
     const int nk = p.K / BK;
@@ -739,108 +730,121 @@ int gemm_splitk_factor(const GemmParams& p) {
     return s;
 }
 
+static int launched() { return hipGetLastError() == hipSuccess ? 0 : -3; }
+
+static int launch_splitk_reduce(const GemmParams& p, hipStream_t stream) {
+    const size_t quads = (size_t)p.M * p.N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+    return launched();
+}
+
+#ifdef SRH_TUNING
+// Probe builds only (tools/probes/build_probes.sh, -DSRH_TUNING): kernel / ablation selection by number (GemmParams::variant or
+// SRH_GEMM_VARIANT).  Returns false when the number names no kernel of this file (the product dispatch then runs).  None of this exists
+// in libsamroad_hip.so.
+static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, int variant, int* rc) {
+    const int grid = ((p.M + 127) / 128) * (p.N / 128);
+    const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
+    const int sk = p.split_ws && p.splitk > 1 ? p.splitk : 1;
+    *rc = -2;
+    if (variant >= 50 && variant <= 62) { *rc = launch_gemm_q192(p, stream, variant - 50); return true; }      // z192's predecessor and its ablations
+    if (variant >= 70 && variant <= 70 + z192_var_count()) { *rc = launch_gemm_z192(p, stream, variant - 70); return true; }
+    switch (variant) {
+        case 1: *rc = launch_cfg<0, 2, 2, 2, 2>(p, stream); return true;                                     // register-staged 128 x 128
+        case 2: if (p.N % 256 == 0 && p.M >= 2048) { *rc = launch_cfg<0, 4, 2, 2, 4>(p, stream); return true; } return false;
+        case 4: hipLaunchKernelGGL((gemm_glds_kernel<0, 1>), dim3(grid), dim3(256), 65536 / 2, stream, p); break;      // one-stage
+        case 11: hipLaunchKernelGGL((gemm_glds_kernel<1, 2>), dim3(grid), dim3(256), 65536, stream, p); break;         // no DMA in the k-loop
+        case 12: hipLaunchKernelGGL((gemm_glds_kernel<2, 2>), dim3(grid), dim3(256), 65536, stream, p); break;         // no reads / MFMA
+        case 20: hipLaunchKernelGGL(gemm_glds256_kernel<0>, g256, dim3(512), 131072, stream, p); break;                // 256 x 256 whatever the tile count
+        case 21: hipLaunchKernelGGL(gemm_glds256_kernel<1>, g256, dim3(512), 131072, stream, p); break;
+        case 22: hipLaunchKernelGGL(gemm_glds256_kernel<2>, g256, dim3(512), 131072, stream, p); break;
+        case 30: case 31: {                        // 128 x 160 tiles without / with the caller's split-K
+            if (p.N % 160 != 0) return true;
+            GemmParams q = p;
+            q.splitk = variant == 31 ? sk : 1;
+            hipLaunchKernelGGL(gemm_glds160_kernel, dim3(((p.M + 127) / 128) * (p.N / 160), q.splitk), dim3(256), 73728, stream, q);
+            *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
+            return true;
+        }
+        case 40: case 41:                          // the ring kernel, 4 / 3 stages, with the caller's split-K
+            if (variant == 40) hipLaunchKernelGGL((gemm_ring_kernel<4>), dim3(grid, sk), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid, sk), dim3(256), 0, stream, p);
+            *rc = sk > 1 ? launch_splitk_reduce(p, stream) : launched();
+            return true;
+        default: return false;
+    }
+    *rc = launched();
+    return true;
+}
+#endif
+
+// Kernel choice by shape — the whole product dispatch:
+//   3x3 conv (neck)                                     -> register-staged implicit GEMM
+//   big fp16-output layers with a bias (ViT-B blocks)   -> gemm_z192 (generated body, persistent 256 x 192 tiles, deferred epilogue)
+//   M >= 4096, N % 256 == 0, tiles fill the chip        -> 256 x 256 LDS-DMA tiles
+//   small M (ViT-L / ViT-H at 256 px)                   -> 128 x 160 tiles | 128 x 128 split-K + ordered reduce | 3-stage ring
+//   everything else                                     -> 128 x 128 LDS-DMA tiles, two workgroups per CU
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
     if (p.N % 128 != 0 || p.K % BK != 0) return -2;
-    if (p.conv_S > 0 && (p.conv_C % BK != 0)) return -2;
-    if (p.conv_S > 0) return launch_cfg<1, 2, 2, 2, 2>(p, stream);
-#ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): kernel / ablation selection by number
-    static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
-    const int variant = p.variant ? p.variant : env_variant;
-    if (variant >= 50 && variant <= 62) return launch_gemm_q192(p, stream, variant - 50);
-    if (variant >= 70 && variant <= 76) return launch_gemm_z192(p, stream, variant - 70);
-#else
-    const int variant = 0;
-#endif
-    // big fp16-output layers: persistent 256x192 kernel with the deferred epilogue (gemm_q192.hip)
-    if (p.a_blocked16 || p.out_blocked16) {     // only gemm_z192 understands the blocked-16 layout
-        if (variant == 0 && q192_preferred(p) && z192_supported(p)) return launch_gemm_z192(p, stream);
-        return -2;
-    }
-    if (variant == 0 && q192_preferred(p)) {
-        // hand-scheduled successor (gemm_z192.hip) wherever it applies (bias, no activation / GELU); q192 keeps the rest
+    if (p.conv_S > 0) return p.conv_C % BK != 0 ? -2 : launch_cfg<1, 2, 2, 2, 2>(p, stream);
 #ifdef SRH_TUNING
-        static const bool use_z192 = !(getenv("SRH_GEMM_Z192") && atoi(getenv("SRH_GEMM_Z192")) == 0);    // probe builds: A/B against q192
-        if (!use_z192) return launch_gemm_q192(p, stream, 0);
+    static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
+    { int rc; if ((p.variant || env_variant) && launch_gemm_probe_variant(p, stream, p.variant ? p.variant : env_variant, &rc)) return rc; }
+    const bool have_tables = true;               // launch_gemm_z192 falls back to a probe-owned table cache
+#else
+    const bool have_tables = p.ztab != nullptr;
 #endif
-        if (z192_supported(p)) return launch_gemm_z192(p, stream);
-        return launch_gemm_q192(p, stream, 0);
-    }
-    if (variant == 1) return launch_cfg<0, 2, 2, 2, 2>(p, stream);
-    if (variant == 2 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<0, 4, 2, 2, 4>(p, stream);
-    // dynamic-LDS opt-in is per device (a function attribute lives in the device's code object): one bit per device
-    static unsigned attr_set = 0;
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    if (!(attr_set & (1u << (dev_ & 31)))) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds160_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr_set |= 1u << (dev_ & 31);
-    }
-    // 256x256 tiles halve the L2->LDS traffic per FLOP but there are only 256 CUs: use them when the tile
-    // count fills the chip evenly (<= one round, or >= 80 % occupancy of the last round), else 128x128.
+    if (p.a_blocked16 || p.out_blocked16)        // only gemm_z192 understands the blocked-16 layout
+        return have_tables && z192_preferred(p) ? launch_gemm_z192(p, stream) : -2;
+    if (have_tables && z192_preferred(p)) return launch_gemm_z192(p, stream);
+
+    static OncePerDevice opt_in;                 // dynamic-LDS opt-in of this file's LDS-DMA kernels, once per device
+    if (!opt_in.run([] {
+            const std::pair<const void*, int> k[] = {
+                {reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds160_kernel), 73728},
+                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072},
+#ifdef SRH_TUNING
+                {reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), 65536},
+                {reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), 65536}, {reinterpret_cast<const void*>(gemm_glds256_kernel<1>), 131072},
+                {reinterpret_cast<const void*>(gemm_glds256_kernel<2>), 131072},
+#endif
+            };
+            for (const auto& f : k)
+                if (hipFuncSetAttribute(f.first, hipFuncAttributeMaxDynamicSharedMemorySize, f.second) != hipSuccess) return false;
+            return true;
+        }))
+        return -3;
+
+    // 256x256 tiles halve the L2->LDS traffic per FLOP but there are only 256 CUs: use them when the tile count fills the chip evenly
+    // (<= one round, or >= 80 % occupancy of the last round).  Not for short-K layers (decoder ConvT: K = 128 / 256): those are all
+    // prologue + epilogue, and two 128x128 workgroups per CU overlap each other's store tail.
     const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
     const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
-    // short-K layers (decoder ConvT: K = 128 / 256) are all prologue + epilogue: two 128x128 workgroups per CU overlap each
-    // other's store tail, one 256x256 workgroup cannot (SRH_GEMM_SHORTK256=1 restores the old choice)
-    const bool shortk256 = false;
-    const bool short_k = p.K <= 256 && !shortk256 && variant < 20;
-    if (variant != 3 && variant != 4 && variant != 11 && variant != 12 && p.N % 256 == 0 && p.M >= 4096 && !short_k && (fits256 || variant >= 20)) {
-        const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
-        if (variant == 21) hipLaunchKernelGGL(gemm_glds256_kernel<1>, g256, dim3(512), 131072, stream, p);
-        else if (variant == 22) hipLaunchKernelGGL(gemm_glds256_kernel<2>, g256, dim3(512), 131072, stream, p);
-        else hipLaunchKernelGGL(gemm_glds256_kernel<0>, g256, dim3(512), 131072, stream, p);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
-    const bool t160 = variant == 0 && use_tile160(p);
-    if (t160 || variant == 30 || variant == 31) {        // (gemm_splitk_factor is 1 whenever use_tile160 holds: one round of 160-wide tiles)
-        // variant 30 / 31 (probe): force the 160-wide tiles without / with split-K (31 needs p.split_ws and p.splitk)
-        const int sk = p.split_ws && p.splitk > 1 && variant != 30 ? p.splitk : 1;
-        if (p.N % 160 != 0) return -2;
-        GemmParams q = p;
-        q.splitk = sk;
-        hipLaunchKernelGGL(gemm_glds160_kernel, dim3(((p.M + 127) / 128) * (p.N / 160), sk), dim3(256), 73728, stream, q);
-        if (sk > 1) {
-            const size_t quads = (size_t)p.M * p.N / 4;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, q);
-        }
-        return hipGetLastError() == hipSuccess ? 0 : -3;
+    if (p.N % 256 == 0 && p.M >= 4096 && p.K > 256 && fits256) {
+        hipLaunchKernelGGL(gemm_glds256_kernel<0>, dim3((unsigned)t256), dim3(512), 131072, stream, p);
+        return launched();
     }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);
-    if (variant == 40 || variant == 41) {          // probe: the ring kernel, 4 / 3 stages, with the caller's split-K
-        const int sk = p.split_ws && p.splitk > 1 ? p.splitk : 1;
-        if (variant == 40) hipLaunchKernelGGL((gemm_ring_kernel<4>), dim3(grid, sk), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid, sk), dim3(256), 0, stream, p);
-        if (sk > 1) {
-            const size_t quads = (size_t)p.M * p.N / 4;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
-        }
-        return hipGetLastError() == hipSuccess ? 0 : -3;
+    if (use_tile160(p)) {                         // one round of 160-wide tiles (gemm_splitk_factor is 1 for these layers)
+        GemmParams q = p;
+        q.splitk = 1;
+        hipLaunchKernelGGL(gemm_glds160_kernel, dim3(((p.M + 127) / 128) * (p.N / 160), 1), dim3(256), 73728, stream, q);
+        return launched();
     }
-    if (variant == 0 && p.split_ws && p.splitk > 1) {
+    if (p.split_ws && p.splitk > 1) {             // deterministic split-K: f32 partials + a reduce pass in ascending slice order
         if (p.splitk != gemm_splitk_factor(p) || p.splitk > (p.K / BK)) return -2;
         hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid, p.splitk), dim3(256), 65536, stream, p);
-        const size_t quads = (size_t)p.M * p.N / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
+        return launch_splitk_reduce(p, stream);
     }
     // at most one 128 x 128 tile per CU and a k-loop long enough to fill a ring: the three-stage ring kernel (one workgroup per CU, the
     // L2 / HBM latency hidden by depth instead of by a second resident workgroup): ViT-H proj 21.3 -> 18.3 us (profiles/r04_gemm_ring_vith.txt)
-    if (variant == 0 && grid <= 256 && p.K / BK >= 12) {
+    if (grid <= 256 && p.K / BK >= 12) {
         hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid), dim3(256), 0, stream, p);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
+        return launched();
     }
-    if (variant == 11) hipLaunchKernelGGL((gemm_glds_kernel<1, 2>), dim3(grid), dim3(256), 65536, stream, p);
-    else if (variant == 12) hipLaunchKernelGGL((gemm_glds_kernel<2, 2>), dim3(grid), dim3(256), 65536, stream, p);
-    else if (variant == 4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1>), dim3(grid), dim3(256), 65536 / 2, stream, p);
-    else hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid), dim3(256), 65536, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid), dim3(256), 65536, stream, p);
+    return launched();
 }
 
 }  // namespace srh

@@ -284,15 +284,9 @@ int launch_sd_tok_selfattn(const float* q, const float* k, const float* v, float
 }
 int launch_sd_t2i_attn(const float* q, const f16* K, const f16* V, float* out, int B, int HW, hipStream_t s) {
     const size_t lds = ((size_t)4 * HW + 16 + 4 * 4 * 17) * 4;
-    // the attribute is per device: one bit per device ordinal (a process may drive several GPUs, one context each)
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_t2i_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done.fetch_or(bit, std::memory_order_relaxed);
-    }
+    static OncePerDevice opt_in;      // the attribute is per device (a process may drive several GPUs, one context each)
+    if (!opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(sd_t2i_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess; }))
+        return -3;
     if (lds > 80 * 1024) return -2;
     hipLaunchKernelGGL(sd_t2i_attn_kernel, dim3(B, 8), dim3(256), lds, s, q, K, V, out, HW);
     return SD_OK();

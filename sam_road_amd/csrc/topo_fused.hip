@@ -283,12 +283,12 @@ int launch_topo_fused(const TopoFusedParams& p, hipStream_t s) {
     if (p.nlayers != 0 && p.nlayers != 3) return -2;
     const int nprm = 128 + 1280 * p.nlayers + 132;
     const int lds = TF_RING + nprm * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topo_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_RING + (128 + 1280 * 3 + 132) * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topo_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_RING + (128 + 132) * 4);
-        attr = true;
-    }
+    static OncePerDevice opt_in;
+    if (!opt_in.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(topo_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_RING + (128 + 1280 * 3 + 132) * 4) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(topo_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_RING + (128 + 132) * 4) == hipSuccess;
+        }))
+        return -3;
     const int groups = (p.nseq + TF_NW - 1) / TF_NW;
     const int grid = groups < 256 ? groups : 256;
     if (p.nlayers == 3) hipLaunchKernelGGL(topo_fused_kernel<3>, dim3(grid), dim3(TF_NW * 64), lds, s, p);

@@ -68,15 +68,18 @@ def test_gemm(ctx, M, N, K, act, resid):
 
 
 @pytest.mark.parametrize("M,N,K,act,use_bias", [
-    (8192, 768, 768, 0, True),        # 128 tiles, one per workgroup: only the exposed (LDS-staged) epilogue
-    (16384, 2304, 768, 1, True),      # 768 tiles = 3 per workgroup: deferred epilogue with GELU riding the next tile
-    (16384, 768, 3072, 2, False),     # 48 k-tiles per tile (four 12-k-tile blocks), ReLU, no bias
-    (12288, 1536, 768, 0, True),      # 384 tiles on 256 workgroups: some walk two tiles, some one
+    (8192, 768, 768, 0, True),        # z192: 128 tiles, one per workgroup: only the exposed (LDS-staged) epilogue
+    (16384, 2304, 768, 1, True),      # z192: 768 tiles = 3 per workgroup: deferred epilogue with GELU riding the next tile
+    (16384, 768, 3072, 0, True),      # z192: 48 k-tiles per tile (four 12-k-tile bodies), one tile per workgroup
+    (12288, 1536, 768, 0, True),      # z192: 384 tiles on 256 workgroups: some walk two tiles, some one
+    (16384, 768, 3072, 2, False),     # ReLU, no bias: no generated body -> the 256 x 256 LDS-DMA kernel (gemm_glds256_kernel)
+    (8192, 1536, 768, 0, False),      # no bias -> the 256 x 256 kernel
+    (2048, 3840, 1280, 0, True),      # ViT-H qkv at 256 px: 480 tiles of 128 x 128, two workgroups per CU, no split-K (gemm_glds_kernel)
 ])
-def test_gemm_persistent_q192(ctx, M, N, K, act, use_bias):
-    """The persistent 256x192 kernel (csrc/gemm_q192.hip) is selected for large fp16-output problems; compare with a plain
-    fp32 torch matmul of the same fp16 operands.  Tolerance: fp16 output of a value rounded to fp16 once before bias /
-    activation and once after -> 2 fp16 ulps of the largest magnitude."""
+def test_gemm_big_fp16_layers(ctx, M, N, K, act, use_bias):
+    """fp16-output layers: the persistent 256 x 192 kernel (csrc/gemm_z192.hip, generated body) where it applies — bias, act none /
+    GELU, N % 192 == 0, K % 768 == 0, >= 128 tiles — and the kernels the dispatch (csrc/gemm.hip launch_gemm) falls back to where it
+    does not; compare with a plain fp32 torch matmul of the same fp16 operands.  Tolerance: one fp16 rounding of the result."""
     g = torch.Generator().manual_seed(M + N + K + act)
     A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
@@ -96,7 +99,151 @@ def test_gemm_persistent_q192(ctx, M, N, K, act, use_bias):
     assert torch.isfinite(o16).all()
     err = (o16.float() - ref).abs().max().item()
     scale = ref.abs().max().item()
-    assert err <= 2.5e-3 * max(scale, 1.0), (err, scale)
+    tolerances.check("op_gemm_f16out[%d,%d,%d,act%d,bias%d] max-abs / scale" % (M, N, K, act, use_bias), err / max(scale, 1.0), tolerances.GEMM_F16_OUT)
+
+
+def to_blocked16(a):
+    """Row-major [M, N] -> the blocked-16 layout of include/samroad_hip.h (srh_op_gemm_ex), flat."""
+    M, N = a.shape
+    return a.reshape(M // 32, 32, N // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def from_blocked16(flat, M, N):
+    return flat.reshape(M // 32, N // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).contiguous().reshape(M, N)
+
+
+def _mlp_operands(M, D, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = (torch.randn(M, D, generator=g) * 0.5).half().cuda()
+    W1 = (torch.randn(H, D, generator=g) * 0.05).half().cuda()
+    W2 = (torch.randn(D, H, generator=g) * 0.05).half().cuda()
+    A[:, 0] += (torch.arange(M, device="cuda") % 64).half() * 0.01      # row- / column-dependent structure: a permutation confined to
+    W1[:, 1] += (torch.arange(H, device="cuda") % 48).half() * 0.01     # an M tail or to odd tile rows cannot pass
+    W2[:, 2] += (torch.arange(D, device="cuda") % 40).half() * 0.01
+    return A, W1, W2, torch.randn(H, generator=g).cuda(), torch.randn(D, generator=g).cuda()
+
+
+# (M, D, H): fc1 = [M, D] x [H, D]^T, fc2 = [M, H] x [D, H]^T.  Tile counts (256 x 192 tiles on 256 workgroups):
+#   (8192, 768, 3072)   fc1 512 = 2 per workgroup            fc2 128 = half the workgroups, one each
+#   (12288, 768, 3072)  fc1 768 = 3 per workgroup            fc2 192
+#   (16384, 768, 3072)  fc1 1024 = 4 (the model at B = 16)   fc2 256 = one each
+#   (65536, 768, 3072)  fc1 4096 = 16 (INFER_BATCH_SIZE 64)  fc2 1024 = 4 per workgroup, A operand 400 MB
+#   (12288, 768, 1536)  fc1 384: some walk two tiles, some one; fc2 K = 1536 = two 12-k-tile bodies
+#   (24576, 1536, 3072) fc1 K = 1536; fc2 768 tiles = 3 per workgroup with the blocked A operand
+_MLP_SHAPES = [(8192, 768, 3072), (12288, 768, 3072), (16384, 768, 3072), (65536, 768, 3072), (12288, 768, 1536), (24576, 1536, 3072)]
+
+
+@pytest.mark.parametrize("M,D,H", _MLP_SHAPES)
+def test_gemm_z192_blocked_fc1_body(ctx, M, D, H):
+    """gemm_z192_kernel<3> — what the model's fc1 runs (csrc/api.hip: GELU, hidden activation WRITTEN in the blocked-16 layout) — alone,
+    against fp32 torch; and bit-identical to the row-major GELU body (kernel<1>) on the same operands."""
+    from sam_road_amd._lib import SRH_GEMM_OUT_BLOCKED16
+    A, W1, _, b1, _ = _mlp_operands(M, D, H, M + H)
+    ref = F.gelu(A.float() @ W1.float().t() + b1)
+    blk = torch.full((M * H,), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm_ex(ctx.handle, _p(A), _p(W1), _p(b1), None, M, H, D, 1, None, _p(blk), SRH_GEMM_OUT_BLOCKED16, None), "srh_op_gemm_ex")
+    rm = torch.full((M, H), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(A), _p(W1), _p(b1), None, M, H, D, 1, None, _p(rm), None), "srh_op_gemm")
+    _sync()
+    got = from_blocked16(blk, M, H)
+    assert torch.isfinite(got).all()
+    tolerances.check("op_gemm_z192_body3[%d,%d,%d] max-abs / scale" % (M, H, D), (got.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1.0),
+                     tolerances.GEMM_F16_OUT)
+    assert torch.equal(got, rm), "blocked-16 and row-major GELU bodies differ"
+
+
+@pytest.mark.parametrize("M,D,H", _MLP_SHAPES)
+def test_gemm_z192_blocked_fc2_body(ctx, M, D, H):
+    """gemm_z192_kernel<2> — the model's fc2 (A operand READ in the blocked-16 layout) — alone, against fp32 torch; and bit-identical to
+    the row-major body (kernel<0>) on the same operand."""
+    from sam_road_amd._lib import SRH_GEMM_A_BLOCKED16
+    _, _, W2, _, b2 = _mlp_operands(M, D, H, M + D)
+    g = torch.Generator().manual_seed(M + 7)
+    Hid = (torch.randn(M, H, generator=g) * 0.5).half().cuda()
+    Hid[:, 0] += (torch.arange(M, device="cuda") % 64).half() * 0.01
+    Hid[:, 5] += (torch.arange(M, device="cuda") // 32 % 16).half() * 0.02            # differs between 32-row blocks
+    ref = Hid.float() @ W2.float().t() + b2
+    hb = to_blocked16(Hid)
+    o_b = torch.full((M, D), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm_ex(ctx.handle, _p(hb), _p(W2), _p(b2), None, M, D, H, 0, None, _p(o_b), SRH_GEMM_A_BLOCKED16, None), "srh_op_gemm_ex")
+    o_r = torch.full((M, D), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(Hid), _p(W2), _p(b2), None, M, D, H, 0, None, _p(o_r), None), "srh_op_gemm")
+    _sync()
+    assert torch.isfinite(o_b).all()
+    tolerances.check("op_gemm_z192_body2[%d,%d,%d] max-abs / scale" % (M, D, H), (o_b.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1.0),
+                     tolerances.GEMM_F16_OUT)
+    assert torch.equal(o_b, o_r), "blocked-16-A and row-major bodies differ"
+
+
+@pytest.mark.parametrize("M,D,H", _MLP_SHAPES)
+def test_gemm_z192_mlp_pair_blocked_hidden(ctx, M, D, H):
+    """fc1 (body 3) -> fc2 (body 2) with the hidden activation handed over in the blocked-16 layout, exactly as srh_encode_decode
+    chains them (csrc/api.hip; reference: the SAM fork's MLPBlock via model.py:245-258), against fp32 torch on the fp16-rounded hidden
+    activation — and against the row-major pair bit for bit."""
+    from sam_road_amd._lib import SRH_GEMM_A_BLOCKED16, SRH_GEMM_OUT_BLOCKED16
+    A, W1, W2, b1, b2 = _mlp_operands(M, D, H, M + D + H)
+    hid_ref = F.gelu(A.float() @ W1.float().t() + b1).half()
+    ref = hid_ref.float() @ W2.float().t() + b2
+    hid = torch.full((M * H,), float("nan"), device="cuda", dtype=torch.half)
+    out = torch.full((M, D), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm_ex(ctx.handle, _p(A), _p(W1), _p(b1), None, M, H, D, 1, None, _p(hid), SRH_GEMM_OUT_BLOCKED16, None), "srh_op_gemm_ex")
+    ctx.check(ctx.lib.srh_op_gemm_ex(ctx.handle, _p(hid), _p(W2), _p(b2), None, M, D, H, 0, None, _p(out), SRH_GEMM_A_BLOCKED16, None), "srh_op_gemm_ex")
+    hid_r = torch.full((M, H), float("nan"), device="cuda", dtype=torch.half)
+    out_r = torch.full((M, D), float("nan"), device="cuda", dtype=torch.half)
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(A), _p(W1), _p(b1), None, M, H, D, 1, None, _p(hid_r), None), "srh_op_gemm")
+    ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(hid_r), _p(W2), _p(b2), None, M, D, H, 0, None, _p(out_r), None), "srh_op_gemm")
+    _sync()
+    assert torch.isfinite(out).all()
+    # the hidden activation the kernel produced can differ from torch's by one fp16 ulp on a few elements (the GELU fit, 1.6e-6): the
+    # pair's bound is the single-GEMM bound plus that
+    tolerances.check("op_gemm_z192_mlp_pair[%d,%d,%d] max-abs / scale" % (M, D, H), (out.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1.0),
+                     tolerances.GEMM_MLP_PAIR)
+    assert torch.equal(out, out_r), "blocked-16 and row-major MLP pairs differ"
+
+
+def test_gemm_ex_refuses_what_no_body_covers(ctx):
+    """The blocked-16 flags exist only for the generated bodies: other combinations return SRH_ERR_UNSUPPORTED instead of running a
+    kernel that would misread the layout."""
+    from sam_road_amd._lib import SRH_GEMM_A_BLOCKED16, SRH_GEMM_OUT_BLOCKED16, SrhError
+    A, W1, W2, b1, b2 = _mlp_operands(8192, 768, 3072, 1)
+    out = torch.zeros((8192 * 3072,), device="cuda", dtype=torch.half)
+    for args in ((A, W1, b1, 8192, 3072, 768, 0, SRH_GEMM_OUT_BLOCKED16),                          # blocked output without GELU
+                 (A, W1, b1, 8192, 3072, 768, 1, SRH_GEMM_OUT_BLOCKED16 | SRH_GEMM_A_BLOCKED16),   # both
+                 (A, W1, None, 8192, 3072, 768, 1, SRH_GEMM_OUT_BLOCKED16),                        # no bias
+                 (A[:1024], W1, b1, 1024, 3072, 768, 1, SRH_GEMM_OUT_BLOCKED16)):                  # 64 tiles: not the persistent kernel's range
+        a, w, b, M, N, K, act, flags = args
+        with pytest.raises(SrhError):
+            ctx.check(ctx.lib.srh_op_gemm_ex(ctx.handle, _p(a), _p(w), _p(b), None, M, N, K, act, None, _p(out), flags, None), "srh_op_gemm_ex")
+    _sync()
+
+
+def test_ctx_memory_is_flat_over_batch_sizes(ctx):
+    """gemm_z192 keeps one tile-order table per (shape, pitch) on the device.  They live in ONE bounded slab the context owns
+    (ZTileTables, csrc/gemm_z192.hip): cycling through more distinct row counts than the slab has slots (32) neither grows the context
+    nor the device's used memory, and a shape that was evicted still computes the same bits when it comes back."""
+    D, N = 768, 1536
+    g = torch.Generator().manual_seed(11)
+    Mmax = 8192 + 256 * 47
+    A = (torch.randn(Mmax, D, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, D, generator=g) * 0.05).half().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = torch.zeros((Mmax, N), device="cuda", dtype=torch.half)
+
+    def run(M):
+        ctx.check(ctx.lib.srh_op_gemm(ctx.handle, _p(A), _p(W), _p(b), None, M, N, D, 0, None, _p(out), None), "srh_op_gemm")
+    run(8192)
+    _sync()
+    first = out[:8192].clone()
+    ctx_bytes = ctx.lib.srh_ctx_device_bytes(ctx.handle)
+    free0 = torch.cuda.mem_get_info()[0]
+    assert ctx_bytes > 0
+    for k in range(48):                                   # 48 distinct shapes through a 32-slot slab
+        run(8192 + 256 * k)
+    run(8192)                                             # evicted meanwhile: rebuilt
+    _sync()
+    assert torch.equal(out[:8192], first)
+    assert ctx.lib.srh_ctx_device_bytes(ctx.handle) == ctx_bytes
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= (8 << 20), "device memory moved while cycling GEMM shapes"
 
 
 def test_gemm_inplace_residual(ctx):

@@ -34,6 +34,10 @@ BATCH_INDEP_SCORE = 5e-4
 ATTN_OP_MAX = 2e-2           # head dims 64 and 80, windowed / global
 ATTN_OP_MEAN = 1.5e-3
 
+# ---- GEMM op level, fp16 output (f32 accumulate, one rounding of the result): max-abs error / max(|ref|, 1) ------------------------------
+GEMM_F16_OUT = 1.5e-3        # half an fp16 ulp of the largest magnitude is 4.9e-4 at |ref| in [4, 8); measured <= 5e-4 in round 4's probe
+GEMM_MLP_PAIR = 2.5e-3       # fc1 -> fc2 against torch on torch's fp16 hidden activation (a one-ulp difference in a few hidden values)
+
 _REC = {}
 
 

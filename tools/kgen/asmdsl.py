@@ -996,3 +996,25 @@ def check_hazards(prog, verbose=False):
         for p_ in problems2:
             print("HAZARD", p_)
     return problems2
+
+
+def check_footprint(prog, first_sgpr=36, first_vgpr=4):
+    """The register contract of a generated one-statement body (sam_road_amd/csrc/asm_body.hpp): it writes no SGPR below `first_sgpr`
+    and no VGPR below `first_vgpr` (the compiler keeps the statement's operands there), and every narrowing of exec is followed by the
+    write that restores all ones — the AMDGPU backend requires exec to leave an asm statement as it entered and accepts neither exec nor
+    m0 on a clobber list (both are reserved registers).  Returns a list of violations."""
+    bad = []
+    exec_state = {"exec_lo": True, "exec_hi": True}        # True = all ones
+    for ins in prog.ins:
+        for f, i in ins.writes:
+            if f == "s" and i < first_sgpr:
+                bad.append(f"writes s{i}: '{ins.text}'")
+            if f == "v" and i < first_vgpr:
+                bad.append(f"writes v{i}: '{ins.text}'")
+            if f == "x" and i in exec_state:
+                exec_state[i] = ins.text.replace(" ", "").endswith(",-1")
+        if ins.kind in ("branch", "barrier", "label") and not all(exec_state.values()):
+            bad.append(f"exec is narrowed across '{ins.text}'")
+    if not all(exec_state.values()):
+        bad.append("exec is not restored at the end of the body")
+    return bad

@@ -24,7 +24,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asmdsl import A, EXEC_HI, EXEC_LO, M0, Prog, S, V, Workgroup, check_hazards, nabs, neg, vabs  # noqa: E402
+from asmdsl import A, EXEC_HI, EXEC_LO, M0, Prog, S, V, Workgroup, check_footprint, check_hazards, nabs, neg, vabs  # noqa: E402
 
 # ---------------------------------------------------------------------------------------------- fixed register map
 KARG, BID, WAVE = S(36, 2), S(38), S(39)
@@ -891,16 +891,14 @@ def write_inc(path, prog):
             f.write('"' + ln.replace("\\", "\\\\").replace('"', '\\"') + '\\n"\n')
 
 
-VARIANTS = {       # probe builds: tools/probes/gemm_probe variants 71..76 (ablations give wrong results).  The sets measured in round 4
-    # (profiles/r04_z192_*.txt) were edited here between runs; this is the last one.
-    1: dict(deferred=True, sched=dict(no_epi=True)),                        # k-loops only
-    2: dict(deferred=True, sched=dict(gelu_pk=True)),                       # GELU in packed f32 (12 VALU per element pair instead of 16)
-    3: dict(deferred=True, sched=dict(gelu_pk=True, gap_slots=8, epi_in_dma_gaps=True)),
-    4: dict(deferred=True, sched=dict(no_store=True)),                      # everything but the global stores
-    5: dict(deferred=True, sched=dict(gelu_dummy=1)),                       # the product schedule with every GELU instruction a v_mov
-    6: dict(deferred=False, sched=dict()),                                  # exposed epilogue after every tile
+# Probe builds (tools/probes/build_probes.sh): schedule variants 1..N = tools/probes/gemm_probe variants 71..70+N, each generated for
+# act 0 and act 1.  Keys: deferred, sched (both activations) / sched_act1 (GELU body only), out_blocked (the act-1 body writes the
+# blocked-16 layout: what the model's fc1 runs), ablation (True: wrong results by construction).  The sets measured in rounds 4 / 5
+# (profiles/r04_z192_*.txt, r05_z192_*.txt) were edited here between runs; this is the last one.
+VARIANTS = {
+    1: dict(deferred=True, sched=dict(no_epi=True), ablation=True),        # k-loops only
+    2: dict(deferred=True, sched=dict()),                                   # the product schedule (control: same code path as 70)
 }
-
 
 PRODUCT_BODIES = {      # gemm_z192.hip includes gemm_z192_body_<name>.inc
     "act0": dict(act=0),                              # qkv, proj (row-major in, row-major out)
@@ -913,7 +911,34 @@ PRODUCT_BODIES = {      # gemm_z192.hip includes gemm_z192_body_<name>.inc
 def variant_gen(k, act):
     kw = VARIANTS[k]
     sched = kw.get("sched_act1", kw["sched"]) if act == 1 else kw["sched"]
-    return ZGen(act=act, deferred=kw["deferred"], sched=sched)
+    return ZGen(act=act, deferred=kw["deferred"], sched=sched, out_blocked=bool(kw.get("out_blocked")) and act == 1)
+
+
+def write_variant_kernels(path):
+    """tools/probes/build/z192_var_kernels.inc: the C++ side of the variants (included by gemm_z192.hip under SRH_TUNING)."""
+    n = max(VARIANTS)
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/kgen/gemm_z192_gen.py --variants — probe builds only.\n")
+        f.write(f"#define Z_NVAR {n}\n")
+        f.write("static const int z_var_ob_tab[Z_NVAR + 1] = {0, " + ", ".join(str(int(bool(VARIANTS.get(k, {}).get("out_blocked")))) for k in range(1, n + 1)) + "};\n")
+        f.write("int z192_var_count() { return Z_NVAR; }\n")
+        f.write("int z192_var_out_blocked(int var) { return var >= 1 && var <= Z_NVAR ? z_var_ob_tab[var] : 0; }\n")
+        f.write("template <int ACT, int VAR>\n__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))\nvoid gemm_z192_var_kernel(ZParams p) {\n")
+        f.write("    const auto karg = __builtin_amdgcn_kernarg_segment_ptr();\n    const unsigned bid = blockIdx.x, tid = threadIdx.x;\n")
+        f.write("    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();\n")
+        for k in sorted(VARIANTS):
+            for act in (0, 1):
+                f.write(f"    if (VAR == {k} && ACT == {act}) {{ asm volatile(\n#include \"z192_var{k}_act{act}.inc\"\n        :: \"s\"(karg), \"s\"(bid), \"v\"(tid) : Z_CLOBBERS); }}\n")
+        f.write("    if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0_;\n}\n")
+        f.write("template <int VAR>\nstatic void z_var_launch(const ZParams& z, int act, int grid, hipStream_t stream) {\n")
+        f.write("    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_z192_var_kernel<0, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);\n")
+        f.write("    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_z192_var_kernel<1, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, Z_LDS);\n")
+        f.write("    if (act == 1) hipLaunchKernelGGL((gemm_z192_var_kernel<1, VAR>), dim3(grid), dim3(256), Z_LDS, stream, z);\n")
+        f.write("    else hipLaunchKernelGGL((gemm_z192_var_kernel<0, VAR>), dim3(grid), dim3(256), Z_LDS, stream, z);\n}\n")
+        f.write("static int z_var_dispatch(const ZParams& z, int act, int grid, hipStream_t stream, int var) {\n    switch (var) {\n")
+        for k in sorted(VARIANTS):
+            f.write(f"        case {k}: z_var_launch<{k}>(z, act, grid, stream); break;\n")
+        f.write("        default: return -2;\n    }\n    return hipGetLastError() == hipSuccess ? 0 : -3;\n}\n")
 
 
 def main():
@@ -924,7 +949,10 @@ def main():
                 prog = variant_gen(k, act).kernel()
                 hz = check_hazards(prog)
                 assert not hz, hz[:5]
+                fp = check_footprint(prog)
+                assert not fp, fp[:5]
                 write_inc(os.path.join(sys.argv[2], f"z192_var{k}_act{act}.inc"), prog)
+        write_variant_kernels(os.path.join(sys.argv[2], "z192_var_kernels.inc"))
         return
     write_meta(os.path.join(root, "sam_road_amd", "csrc", "gemm_z192_meta.inc"))
     for name, kw in PRODUCT_BODIES.items():
@@ -933,6 +961,8 @@ def main():
         for h in hz[:20]:
             print("HAZARD:", h)
         assert not hz, f"{len(hz)} hazards"
+        fp = check_footprint(prog)
+        assert not fp, fp[:5]
         path = os.path.join(root, "sam_road_amd", "csrc", f"gemm_z192_body_{name}.inc")
         write_inc(path, prog)
         print(f"{name}: {prog.n_real()} instructions -> {path}")

@@ -7,13 +7,14 @@ cd "$(dirname "$0")/../.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING -Itools/probes/build"
 mkdir -p tools/probes/build
-python3 tools/kgen/gemm_z192_gen.py --variants tools/probes/build   # z192_var{1..6}_act{0,1}.inc: the schedule variants under test
+python3 tools/kgen/gemm_z192_gen.py --variants tools/probes/build   # z192_var{k}_act{0,1}.inc + z192_var_kernels.inc: the schedule variants under test
 python3 tools/kgen/attn_g64_gen.py                                  # attn_g64_body.inc / _meta.inc: the asm global attention experiment (probe only)
 python3 tools/kgen/attn_g64_gen.py --variants tools/probes/build    # attn_g64_var{1..8}.inc: its schedule ablations
 mkdir -p tools/probes/build
-for f in gemm gemm_q192 gemm_z192; do
+for f in gemm gemm_z192; do
   $HIPCC $FLAGS -c sam_road_amd/csrc/$f.hip -o tools/probes/build/$f.o &
 done
+$HIPCC $FLAGS -Isam_road_amd/csrc -c tools/probes/gemm_q192.hip -o tools/probes/build/gemm_q192.o &      # z192's predecessor: probe builds only (A/B history)
 $HIPCC $FLAGS -c tools/probes/gemm_probe.hip -o tools/probes/build/gemm_probe.o &
 wait
 $HIPCC --offload-arch=gfx950 tools/probes/build/gemm_probe.o tools/probes/build/gemm.o tools/probes/build/gemm_q192.o tools/probes/build/gemm_z192.o -o tools/probes/gemm_probe

@@ -114,6 +114,7 @@ int main(int argc, char** argv) {
             if (variant == 0) { GemmParams t = g; t.variant = 0; const int sk = gemm_splitk_factor(t); if (sk > 1) { g.splitk = sk; g.split_ws = ws; } }
             if (variant == 31) { g.splitk = 4; g.split_ws = ws; }
             if (variant == 77) { g.variant = 70; g.out_blocked16 = 1; }
+            if (variant > 70 && variant <= 70 + z192_var_count() && z192_var_out_blocked(variant - 70) && s.act == 1) g.out_blocked16 = 1;
             if (variant == 78) { g.variant = 70; g.a_blocked16 = 1; g.A = dA_blk; }
             return g;
         };
@@ -125,7 +126,7 @@ int main(int argc, char** argv) {
             const int rc = launch_gemm(g, 0);
             CK(hipDeviceSynchronize());
             const f16* o16_cmp = o16;
-            if (variants[vi] == 77) { from_blocked16<<<2048, 256>>>(o16, o16_rm, s.M, s.N); o16_cmp = o16_rm; }
+            if (g.out_blocked16) { from_blocked16<<<2048, 256>>>(o16, o16_rm, s.M, s.N); o16_cmp = o16_rm; }
             diff_kernel<<<1024, 256>>>(ref, s.f16out ? nullptr : o32, s.f16out ? o16_cmp : nullptr, nO, dmax, dmax + 1);
             float h[2]; CK(hipMemcpy(h, dmax, 8, hipMemcpyDeviceToHost));
             printf("  check %-5s variant %3d rc=%d  max|diff|=%.3e  (max|ref|=%.2f)\n", s.name, variants[vi], rc, h[0], h[1]);
@@ -179,7 +180,7 @@ int main(int argc, char** argv) {
             const double fl = 2.0 * s.M * (double)s.N * s.K;
             printf("%-5s M=%d N=%d K=%d variant %3d: median %8.1f us (%7.1f TFLOP/s)   min %8.1f us (%7.1f)", s.name, s.M, s.N, s.K,
                    variants[vi], med * 1e3, fl / med / 1e9, mn * 1e3, fl / mn / 1e9);
-            if (variants[vi] > 70 && variants[vi] <= 76) {       // z192 probe variants record their shader-clock ticks per workgroup
+            if (variants[vi] > 70 && variants[vi] <= 70 + z192_var_count()) {       // z192 probe variants record their shader-clock ticks per workgroup
                 CK(hipMemset(ddbg, 0, 256 * 8));
                 const GemmParams g = make(variants[vi]);
                 hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));

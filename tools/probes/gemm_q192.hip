@@ -1,3 +1,6 @@
+// PROBE BUILDS ONLY (tools/probes/build_probes.sh; not part of libsamroad_hip.so since round 5): the round 1-3 predecessor of
+// sam_road_amd/csrc/gemm_z192.hip, kept for same-box A/B measurements (gemm_probe variants 50..62).
+//
 // Persistent 256(M) x 192(N) x 64 f16 MFMA GEMM with a DEFERRED, register-held epilogue:
 //     OUT16[M,N] = act(A[M,K] * W[N,K]^T + bias)          (fp16 out, fp32 accumulate)
 // for the four big linear layers of every SAM ViT block (qkv, proj, fc1, fc2 — SURVEY.md §2.1 K4/K7/K8).
@@ -422,10 +425,6 @@ void gemm_q192_kernel(GemmParams p) {
                 __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_*>(reinterpret_cast<char*>(p.out_f16) + obase + (size_t)row * p.ldc16 * 2 + col));
             }
     }
-}
-
-bool q192_preferred(const GemmParams& p) {   // enough tiles to occupy the chip
-    return q192_supported(p) && (p.M / 256) * (p.N / 192) >= 128;
 }
 
 bool q192_supported(const GemmParams& p) {

@@ -167,12 +167,13 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
     return res
 
 
-def scene_block(args, net, sd, dev, rank, world, distributed):
+def scene_block(args, net, sd, dev, rank, world, distributed, box):
     """BASELINE configs[3]: ms per synthetic 2048 x 2048 CityScale scene (toponet_vitb_512_cityscale.yaml tiling: 256 tiles of
     512^2, INFER_BATCH_SIZE 64) through the CLI's scene loop — end to end to the edge list.  N = 1: the one-GPU pipeline
     (infer_imgs).  N > 1: every scene's tiles are SHARDED over the ranks (banded canvas reduce, point broadcast, vote gather
-    over RCCL), scenes pipelined across the ranks (inferencer._infer_imgs_tile_sharded).  `rccl_ranks` is an on-device
-    all-reduce of ones: the number of ranks the collective library actually connected."""
+    over RCCL): first scene by scene, then pipelined across the ranks (inferencer._infer_imgs_tile_sharded).  `rccl_ranks` is an
+    on-device all-reduce of ones: the number of ranks the collective library actually connected.  Results go into box["scene"] as
+    they complete (the caller runs this under a deadline)."""
     import numpy as np
     import torch.distributed as dist
     from sam_road_amd import Config
@@ -201,39 +202,62 @@ def scene_block(args, net, sd, dev, rank, world, distributed):
         t = torch.ones(1, device=dev)
         dist.all_reduce(t)
         rccl_ranks = int(t.item())
-    run = (lambda n, st: list(inf._infer_imgs_tile_sharded(net, stream(n), cfg, dev, stats=st))) if distributed else \
-          (lambda n, st: list(inf.infer_imgs(net, stream(n), cfg, dev, tile_sharded=False)))
-    run(2, {})                                         # warm-up: staging pools, workspaces, first-call costs
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    stats = {}
-    t0 = time.perf_counter()
-    res = run(args.scenes, stats)
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    per_rank = None
-    if distributed:
-        keys = ("pass1_queue_ms", "points_host_ms", "pass2_ms", "merge_host_ms", "canvas_bytes", "points_bytes", "votes_bytes")
-        mine = torch.tensor([el] + [stats.get(k, 0.0) / max(args.scenes, 1) for k in keys], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        el = max(a[0].item() for a in allr)
-        per_rank = [dict(zip(keys, [round(v, 3) for v in a[1:].tolist()])) for a in allr]
-    if rank != 0:
-        return None
-    last = res[-1]
-    return {"what": "synthetic 2048x2048 u8 CityScale-sized scenes, toponet_vitb_512_cityscale.yaml tiling (256 tiles of 512^2, batch 64), "
-                    "pass 1 + graph points + pass 2 + edge vote, end to end (BASELINE configs[3])",
-            "mode": (f"tiles of every scene sharded over {world} ranks, scenes pipelined across the ranks" if distributed
-                     else "one GPU, scenes software-pipelined (infer_imgs)"),
-            "scenes": args.scenes, "ms_per_scene": round(1e3 * el / args.scenes, 3), "scenes_per_s": round(args.scenes / el, 3),
-            "n_gpus": world, "rccl_ranks": rccl_ranks,
-            "per_rank_per_scene": per_rank,
-            "bytes_per_scene_note": "canvas = banded f32 canvas reduce to rank 0; points = int64 [N,2] broadcast; votes = (key, sum, count, first) gather",
-            "graph_points": int(last[0].shape[0]), "edges": int(last[1].shape[0])}
+    def timed(run):
+        run(2, {})                                         # warm-up: staging pools, workspaces, first-call costs
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        stats = {}
+        t0 = time.perf_counter()
+        res = run(args.scenes, stats)
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        per_rank = None
+        if distributed:
+            keys = ("pass1_queue_ms", "points_host_ms", "pass2_ms", "merge_host_ms", "canvas_bytes", "points_bytes", "votes_bytes")
+            mine = torch.tensor([el] + [stats.get(k, 0.0) / max(args.scenes, 1) for k in keys], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            el = max(a[0].item() for a in allr)
+            per_rank = [dict(zip(keys, [round(v, 3) for v in a[1:].tolist()])) for a in allr]
+        return res, el, per_rank
+
+    what = ("synthetic 2048x2048 u8 CityScale-sized scenes, toponet_vitb_512_cityscale.yaml tiling (256 tiles of 512^2, batch 64), "
+            "pass 1 + graph points + pass 2 + edge vote, end to end (BASELINE configs[3])")
+    if not distributed:
+        res, el, _ = timed(lambda n, st: list(inf.infer_imgs(net, stream(n), cfg, dev, tile_sharded=False)))
+        last = res[-1]
+        box["scene"] = {"what": what, "mode": "one GPU, scenes software-pipelined (infer_imgs)", "scenes": args.scenes,
+                        "ms_per_scene": round(1e3 * el / args.scenes, 3), "scenes_per_s": round(args.scenes / el, 3), "n_gpus": world,
+                        "rccl_ranks": rccl_ranks, "graph_points": int(last[0].shape[0]), "edges": int(last[1].shape[0])}
+        return
+    # N > 1, two loops over the same scenes.  First the SERIAL tile-sharded loop (infer_one_img scene by scene: the library's default
+    # under torch.distributed, its three exchange steps strictly in sequence) — its figure is in the box before the second loop starts,
+    # so a hang there cannot cost it.  Then the PIPELINED loop (opt-in in the library: it has only ever run on gloo), whose figure
+    # replaces `ms_per_scene` when it completes; both are reported.
+    res, el, _ = timed(lambda n, st: list(inf.infer_imgs(net, stream(n), cfg, dev, tile_sharded=True, pipelined=False)))
+    out = None
+    if rank == 0:
+        last = res[-1]
+        out = {"what": what, "mode": f"tiles of every scene sharded over {world} ranks, scene by scene (serial loop)", "scenes": args.scenes,
+               "ms_per_scene": round(1e3 * el / args.scenes, 3), "scenes_per_s": round(args.scenes / el, 3), "n_gpus": world,
+               "rccl_ranks": rccl_ranks, "serial_loop_ms_per_scene": round(1e3 * el / args.scenes, 3),
+               "graph_points": int(last[0].shape[0]), "edges": int(last[1].shape[0]),
+               "pipelined_loop": "did not complete (see error / deadline)"}
+        box["scene"] = out
+    res, el, per_rank = timed(lambda n, st: list(inf._infer_imgs_tile_sharded(net, stream(n), cfg, dev, stats=st)))
+    if rank == 0:
+        last = res[-1]
+        same = int(last[0].shape[0]) == out["graph_points"] and int(last[1].shape[0]) == out["edges"]
+        out = dict(out, mode=f"tiles of every scene sharded over {world} ranks, scenes pipelined across the ranks",
+                   ms_per_scene=round(1e3 * el / args.scenes, 3), scenes_per_s=round(args.scenes / el, 3),
+                   pipelined_loop="completed; same graph as the serial loop" if same else "completed; GRAPH DIFFERS from the serial loop",
+                   pipelined_loop_ms_per_scene=round(1e3 * el / args.scenes, 3), per_rank_per_scene=per_rank,
+                   bytes_per_scene_note="each rank's OWN traffic: canvas = its band of the two f32 canvases shipped to rank 0 (rank 0: all it "
+                                        "receives); points = int64 [N,2] broadcast (rank 0: sent to every peer); votes = its (key, sum, count, first) rows of the gather")
+        box["scene"] = out
 
 
 def plumbing_cpu(args):
@@ -579,7 +603,7 @@ def main():
         def _scene():
             try:
                 torch.cuda.set_device(dev)          # the current device is per thread
-                box["scene"] = scene_block(args, net, sd, dev, rank, world, distributed)
+                scene_block(args, net, sd, dev, rank, world, distributed, box)
             except Exception as e:      # noqa: BLE001 — reported in the line
                 box["error"] = f"{type(e).__name__}: {e}"[:400]
         th = threading.Thread(target=_scene, daemon=True)
@@ -587,8 +611,8 @@ def main():
         th.join(timeout=args.scene_timeout)
         hung = th.is_alive()
         if rank == 0:
-            out["scene"] = box.get("scene") if "scene" in box else \
-                {"error": box.get("error", f"no result after {args.scene_timeout:.0f} s (hang in an exchange step?)"), "n_gpus": world}
+            why = box.get("error") or (f"no result after {args.scene_timeout:.0f} s (hang in an exchange step?)" if hung else None)
+            out["scene"] = dict(box.get("scene") or {"n_gpus": world}, **({"error": why} if why else {}))
         if hung or "error" in box:
             if rank == 0:
                 print(json.dumps(out), flush=True)

@@ -98,18 +98,21 @@ def reduce_canvases(kp, road, dst=0, bands=None):
             if outside != 0.0:
                 raise RuntimeError(f"reduce_canvases: rank {rank} holds canvas data outside its band [{x0}, {x1})")
         if x1 > x0:
-            dist.send(torch.stack([kp[:, x0:x1], road[:, x0:x1]]).contiguous(), dst=dst)
+            band = torch.stack([kp[:, x0:x1], road[:, x0:x1]]).contiguous()
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, band, dst)]):
+                q.wait()
         return
-    # all receives are posted at once (the senders finish pass 1 at about the same time); the bands are then added in rank order,
-    # which fixes the summation order of a pixel shared by several bands
-    parts, reqs = {}, []
+    # all receives are posted at once, as ONE batched group (ncclGroupStart / End under RCCL: N - 1 un-batched irecv calls would each
+    # be their own communicator operation, serialised in call order); the senders finish pass 1 at about the same time.  The bands are
+    # then added in rank order, which fixes the summation order of a pixel shared by several bands
+    parts, ops = {}, []
     for r in range(world):
         x0, x1 = bands[r]
         if r == dst or x1 <= x0:
             continue
         parts[r] = torch.empty((2, kp.shape[0], x1 - x0), dtype=kp.dtype, device=kp.device)
-        reqs.append(dist.irecv(parts[r], src=r))
-    for q in reqs:
+        ops.append(dist.P2POp(dist.irecv, parts[r], r))
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
         q.wait()
     for r in sorted(parts):
         x0, x1 = bands[r]

@@ -624,7 +624,7 @@ class _SceneJob:
     pass
 
 
-def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
+def infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None):
     """infer_one_img over a sequence of scenes, as a generator of the same tuples in the same order — software-pipelined on
     one GPU: while the device runs pass 1 of scene i+1, the host does scene i's mask -> points -> pass-2 queries; scene i's
     TopoNet batches are queued behind that pass 1 and its edge vote runs while scene i+2 is on the device.  One compute stream
@@ -632,10 +632,20 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None):
     canvases / embeddings are its own tensors, so nothing of the context is double-buffered.  The results are those of
     infer_one_img bit for bit (same kernels in the same order per scene).  The reference's loop (inferencer.py:289-349) is
     strictly serial; this is what the CLI uses.  tile_sharded (default: torch.distributed is initialised) selects the other
-    multi-GPU mode instead — every scene's tiles split over the ranks through infer_one_img, one scene at a time; with
-    tile_sharded=False each rank runs its own scenes through the pipeline and no collective is issued."""
+    multi-GPU mode instead — every scene's tiles split over the ranks; with tile_sharded=False each rank runs its own scenes through
+    the pipeline and no collective is issued.  The tile-sharded mode has two loops: the SERIAL one (default) — infer_one_img scene by
+    scene, its three exchange steps strictly in sequence — and the PIPELINED one (_infer_imgs_tile_sharded; `pipelined=True`, config
+    key TILE_SHARD_PIPELINE, CLI `--shard tiles-pipelined`), which interleaves the band reduce of scene i+1 with the point broadcast
+    and vote gather of scene i.  The pipelined loop has only ever run on gloo / CPU (no multi-GPU box was available to the builder:
+    DESIGN.md §6), so it stays opt-in until an RCCL run exists; both give the same results (tests/test_distributed_cpu.py)."""
     if D.is_distributed() if tile_sharded is None else tile_sharded:
-        yield from _infer_imgs_tile_sharded(net, imgs, config, device)
+        if pipelined is None:
+            pipelined = bool(config.TILE_SHARD_PIPELINE)          # a missing key is an empty (falsy) Config
+        if pipelined:
+            yield from _infer_imgs_tile_sharded(net, imgs, config, device)
+        else:
+            for img in imgs:
+                yield infer_one_img(net, img, config, device=device)
         return
     device = torch.device(device) if device is not None else next(net.parameters()).device
     lane = _Lane(device)
@@ -779,7 +789,9 @@ def _infer_imgs_tile_sharded(net, imgs, config, device=None, stats=None):
         bands = D.tile_bands(job.all_xy, int(config.PATCH_SIZE), world) if world > 1 else None
         D.reduce_canvases(kp_c, road_c, dst=0, bands=bands)
         if bands is not None:
-            stats["canvas_bytes"] += D.canvas_bytes(bands, job.img.shape[0])
+            # this rank's own share: the band it ships to rank 0 (rank 0: what it receives), so that per-rank statistics are per rank
+            x0, x1 = bands[rank]
+            stats["canvas_bytes"] += D.canvas_bytes(bands, job.img.shape[0]) if rank == 0 else 2 * 4 * job.img.shape[0] * max(0, x1 - x0)
         job.masks = job.e1 = None
         if rank == 0:
             kp_u8, road_u8 = net.scene_normalise(kp_c, road_c, job.xy_dev)
@@ -805,7 +817,7 @@ def _infer_imgs_tile_sharded(net, imgs, config, device=None, stats=None):
         t1 = time.perf_counter()
         stats["points_host_ms"] += 1e3 * (t1 - t0)
         graph_points = D.broadcast_points(graph_points, src=0, device=device if world > 1 else None)
-        stats["points_bytes"] += 16 * graph_points.shape[0] * (world - 1)
+        stats["points_bytes"] += 16 * graph_points.shape[0] * ((world - 1) if rank == 0 else 1)     # rank 0: sent to every peer; others: received
         if graph_points.shape[0] == 0:
             return None if rank != 0 else (graph_points, np.zeros((0, 2), dtype=np.int32), kp_mask, road_mask)
         n_pts = graph_points.shape[0]
@@ -914,7 +926,7 @@ def main(argv=None):
     `viz/` renderings and the ground-truth pickle the reference loads but only uses in commented-out code (visualisation,
     SURVEY §2 #17).  Extras: `--images a.png b.npy ...` runs explicit scene files instead of the dataset split; under torchrun
     (one process per GPU) the scenes are dealt round-robin to the ranks (`--shard scenes`, default) or every scene's tiles are split
-    over the ranks (`--shard tiles`), all ranks writing into the one output directory."""
+    over the ranks (`--shard tiles`; `tiles-pipelined` for the software-pipelined loop), all ranks writing into the one output directory."""
     import argparse
     import os
     import pickle
@@ -928,9 +940,10 @@ def main(argv=None):
     ap.add_argument("--output_dir", default=None, help="Name of the output dir, if not specified will use timestamp")
     ap.add_argument("--device", default="cuda", help="device to use (an MI355X: there is no CPU path)")
     ap.add_argument("--images", nargs="*", default=None, help="(extension) explicit scene images instead of the dataset split")
-    ap.add_argument("--shard", choices=("scenes", "tiles"), default="scenes",
+    ap.add_argument("--shard", choices=("scenes", "tiles", "tiles-pipelined"), default="scenes",
                     help="(extension, multi-GPU runs under torchrun) scenes: every rank takes whole scenes, no data-path collective "
-                         "(throughput); tiles: the tiles of every scene are split over the ranks (latency of one scene)")
+                         "(throughput); tiles: the tiles of every scene are split over the ranks, scene by scene (latency of one scene); "
+                         "tiles-pipelined: the same with scene i+1's pass 1 queued before scene i's host stages (opt-in: exercised on gloo only)")
     args = ap.parse_args(argv)
     config = load_config(args.config)
     device = torch.device("cuda") if args.device == "cuda" else torch.device(args.device)
@@ -1010,7 +1023,8 @@ def main(argv=None):
     # the time reported is what the loop spends waiting for results — its sum over the images is the wall time of inference.  PNG
     # encoding and pickling (tens of ms per 2048^2 scene) run on two writer threads so that the loop goes straight back to the GPU.
     total_inference_seconds = 0.0
-    results = infer_imgs(net, scenes(), config, device=device, tile_sharded=world > 1 and not by_scene)
+    results = infer_imgs(net, scenes(), config, device=device, tile_sharded=world > 1 and not by_scene,
+                         pipelined=True if args.shard == "tiles-pipelined" else None)
     with ThreadPoolExecutor(2) as writer:
         pending = []
         for img_id, path in jobs:

@@ -269,7 +269,7 @@ def _cli_rank(world, rank, port, work, out):
         from sam_road_amd import inferencer as inf
         seen = []
 
-        def fake_infer_imgs(net, imgs, config, device=None, tile_sharded=None):
+        def fake_infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None):
             assert tile_sharded is False                      # scene sharding: no collective on the data path
             for im in imgs:
                 seen.append(int(im[:8, :8].astype(np.int64).sum()))
@@ -349,6 +349,15 @@ def _pipe_run(world, rank, port, out, scene_size, overrides, seeds):
         if world > 1:
             got = list(_infer_imgs_tile_sharded(net, iter(imgs), Config(cfg), device="cpu", stats=stats))
             assert list(infer_imgs(net, iter([]), Config(cfg), device="cpu", tile_sharded=True)) == []
+            # infer_imgs under torch.distributed: the SERIAL scene-by-scene loop by default, the pipelined one by config key — same graphs
+            serial = list(infer_imgs(net, iter(imgs), Config(cfg), device="cpu"))
+            piped = list(infer_imgs(net, iter(imgs), Config(dict(cfg, TILE_SHARD_PIPELINE=True)), device="cpu"))
+            for a, b, c in zip(got, serial, piped):
+                assert (a is None) == (b is None) == (c is None) == (rank != 0)
+                if a is not None:
+                    for x, y, z in zip(a, b, c):
+                        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+                        np.testing.assert_array_equal(np.asarray(x), np.asarray(z))
         else:
             got = [infer_one_img(net, im, Config(cfg), device="cpu") for im in imgs]
         out.put((rank, [None if r is None else [np.asarray(a) for a in r] for r in got], stats))

@@ -140,3 +140,27 @@ def test_pass2_batching_sorted_vs_consecutive(pair):
     for a, b in zip(got[True], got[False]):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the box (RCCL over xGMI); gpurun boxes expose one")
+def test_bench_two_gpus_rccl_tile_sharded_scene():
+    """The first thing to run on a multi-GPU box: `python bench.py --gpus 2` (bare form: it re-execs under torch.distributed.run) —
+    RCCL connects both ranks, the packed-weight broadcast, the serial AND the pipelined tile-sharded scene loops complete under RCCL
+    and yield the same graph (sam_road_amd/distributed.py: batched point-to-point band reduce, point broadcast, vote gather)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-reference-gpu", "--no-workloads", "--no-sustained", "--scenes", "3", "--scene-timeout", "300"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(js) == 1, r.stdout[-2000:]
+    line = js[0]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
+    sc = line["scene"]
+    assert "error" not in sc, sc
+    assert sc["rccl_ranks"] == 2 and sc["pipelined_loop"].startswith("completed; same graph"), sc

@@ -80,7 +80,18 @@ K_A, K_W, K_BIAS, K_OUT, K_TABLE = 0, 8, 16, 24, 32
 K_DIMS, K_DIMS2, K_DIMS3 = 48, 64, 80
 KARG_BYTES = 96
 
-GELU_C = [0.00048291164585022967, -0.0071898452371611365, 0.05218537922649359, 0.4595148493607732, 1.1510354141727006, 1.0]
+# exact-erf GELU as  max(x, 0) - |x| 2^(-r(|x|)),  r a polynomial fitted (tools/fit_gelu.py) so that max_a |a 2^-r(a) - a Phi(-a)| is
+# as small as the degree allows.  Highest power first; the last entry is the constant term (1.0 exactly for the round-1 degree-5 fit).
+#   degree 5: 1.6e-6   degree 4: 1.1e-5   degree 3: 9.5e-5   (absolute, over all a >= 0; an fp16 half-ulp is 6.1e-5 at 0.125 <= |y| < 0.25
+#   and 2.4e-4 at 0.5 <= |y| < 1: tools/fit_gelu.py prints the rounded-output error of each degree)
+GELU_FITS = {
+    5: [0.00048291164585022967, -0.0071898452371611365, 0.05218537922649359, 0.4595148493607732, 1.1510354141727006, 1.0],
+    4: [-0.004179672357674636, 0.045596776558867104, 0.46561372080778884, 1.1487885005872824, 1.0002332302268748],
+    3: [0.027115101429684235, 0.49156223219618944, 1.135889844701584, 1.001923220905336],
+}
+EXPOSED_V2 = True       # the product bodies' exposed (last-tile) epilogue: False = the deferred atoms back to back, True = exposed_epilogue_v2
+GELU_DEG = 4            # the product bodies' degree (PRODUCT_BODIES may override per body)
+GELU_C = GELU_FITS[5]
 
 
 class ZGen:
@@ -96,6 +107,8 @@ class ZGen:
         self.out_blocked, self.a_blocked = out_blocked, a_blocked
         self.p = Prog()
         self.sched = sched or {}
+        self.gelu_c = GELU_FITS[self.sched.get("gelu_deg", GELU_DEG)]
+        self.exposed_v2 = bool(self.sched.get("exposed_v2", EXPOSED_V2))
 
     # ------------------------------------------------------------------------------------------ prologue
     def prologue(self):
@@ -227,8 +240,10 @@ class ZGen:
             for k in range(4):
                 p.s_mov_b32(GCP[k][0], float(GELU_C[k + 1]))
         else:
-            for k in range(4):
-                p.s_mov_b32(GC[k], float(GELU_C[k + 1]))
+            # Horner constants after the leading coefficient (VC0): the SGPRs the buffer sizes came in; a constant term of exactly 1.0 is inline
+            for k, c in enumerate(self.gelu_c[1:]):
+                if not (k == len(self.gelu_c) - 2 and c == 1.0):
+                    p.s_mov_b32(GC[k], float(c))
         p.s_and_b32(T0, WAVE, 1)                          # wn again (T0 was reused)
         # bias: LDS read address (wn*96 + 4 fhalf) floats, DMA source offset wave*192 + lane*16
         p.s_mul_i32(T2, T0, 384)
@@ -238,7 +253,7 @@ class ZGen:
         p.s_mul_i32(T2, WAVE, 192)
         p.v_lshlrev_b32(t3, 4, LANE)
         p.v_add_u32(VBD, T2, t3)
-        p.v_mov_b32(VC0, float(GELU_C[0]))
+        p.v_mov_b32(VC0, float(self.gelu_c[0]))
         if self.sched.get("gelu_pk"):
             p.v_mov_b32(VC0P[0], float(GELU_C[0]))
         # tiles of this workgroup: idx = bid, bid + grid, ...; my_tiles = ceil((ntiles - bid) / grid)   (bid < ntiles)
@@ -359,6 +374,31 @@ class ZGen:
             return lambda: (p.ds_read_b128(FRX(set_, j), XF[xslot * 4 + ks], j * 4096), self.lg_log.append("F"))
         return [rx(0), rw(0), rx(1), rx(2), rx(3), rw(1), rw(2)]
 
+    def gelu_k(self, c):
+        """Horner constant c (1 .. degree - 1; constant 0 sits next to the leading coefficient in the first FMA): SGPR, or inline 1.0"""
+        last = c == len(self.gelu_c) - 2
+        return 1.0 if last and self.gelu_c[-1] == 1.0 else GC[c]
+
+    def gelu_inline(self, xs):
+        """Straight-line GELU of the f32 registers xs (4 at a time through the GT temporaries): the exposed epilogue's form."""
+        p = self.p
+        for g0 in range(0, len(xs), 4):
+            x = xs[g0:g0 + 4]
+            r_ = [GT[3 * e] for e in range(len(x))]
+            e_ = [GT[3 * e + 1] for e in range(len(x))]
+            m_ = [GT[3 * e + 2] for e in range(len(x))]
+            for e in range(len(x)):
+                p.v_fma_f32(r_[e], VC0, vabs(x[e]), GC[0])
+            for c in range(1, len(self.gelu_c) - 1):
+                for e in range(len(x)):
+                    p.v_fma_f32(r_[e], r_[e], vabs(x[e]), self.gelu_k(c))
+            for e in range(len(x)):
+                p.v_exp_f32(e_[e], neg(r_[e]))
+            for e in range(len(x)):
+                p.v_max_f32(m_[e], 0, x[e])
+            for e in range(len(x)):
+                p.v_fma_f32(x[e], nabs(x[e]), e_[e], m_[e])
+
     # ------------------------------------------------------------------------------------------ epilogue atoms
     def epi_atoms(self):
         """The finished tile (f32 in SETB: accumulator tile t = 4 i + j at [16t, 16t+16), register 4q+e = row (lane&31) of
@@ -466,22 +506,14 @@ class ZGen:
                                 else:
                                     p.v_fma_f32(r_[e], VC0, vabs(x[e]), GC[0])
                         atom_halves(f1)
-                        for c in (1, 2, 3):
+                        for c in range(1, len(self.gelu_c) - 1):
                             def f2(es, x=x, r_=r_, c=c):
                                 for e in es:
                                     if gd == 1:
                                         p.v_mov_b32(r_[e], x[e])
                                     else:
-                                        p.v_fma_f32(r_[e], r_[e], vabs(x[e]), GC[c])
+                                        p.v_fma_f32(r_[e], r_[e], vabs(x[e]), self.gelu_k(c))
                             atom_halves(f2)
-
-                        def f5(es, x=x, r_=r_):
-                            for e in es:
-                                if gd == 1:
-                                    p.v_mov_b32(r_[e], x[e])
-                                else:
-                                    p.v_fma_f32(r_[e], r_[e], vabs(x[e]), 1.0)
-                        atom_halves(f5)
 
                         def fe(es, r_=r_, e_=e_):
                             for e in es:
@@ -580,6 +612,148 @@ class ZGen:
                             self.vm_log.append("S")
                     atom(2, "vmem", st)
         return atoms
+
+    def wait_tag(self, tag):
+        """s_waitcnt lgkmcnt(n) with n = the LDS operations issued after the youngest one tagged `tag` (a wave's LDS operations return in order)."""
+        if tag not in self.lg_log:
+            return
+        n = 0
+        for k in reversed(self.lg_log):
+            if k == tag:
+                break
+            n += 1
+        n = min(n, 15)
+        self.p.s_waitcnt(lgkmcnt=n)
+        self.lg_log = self.lg_log[len(self.lg_log) - n:]
+
+    def exposed_epilogue_v2(self):
+        """The epilogue of a workgroup's LAST tile, written for latency instead of for gap filling (sched exposed_v2).
+
+        The deferred atoms run back to back leave the store path idle for the first ~3 k ticks (all bias / activation / packing
+        first, then staging and stores block by block with every LDS round trip exposed) and store 96-byte row segments because only
+        14 KiB of LDS are left beside the operand rings (60.6 ticks per store instruction per CU, profiles/r04_store_probe.txt).  When
+        the k-loop has ended, though, X ring slot 2 is free — its last readers passed the last k-tile's barrier and no LDS-DMA piece
+        targets it any more — so a wave stages a whole 32-row x 192-byte block of its tile there and stores full row segments (5.33
+        rows x 192 B per instruction: 46.4 ticks), and the work is ordered row block (j) outer / W block (i) inner with the
+        accumulators drained 16 at a time, so that the stores of row block j - 1 are issued in the middle of row block j's arithmetic:
+        the store path starts ~0.6 k ticks after the last MFMA and stays busy, the VALU work hides behind it.  The bias values of a
+        step are read one step ahead into alternating register sets (the fragment-address registers are dead by now)."""
+        p = self.p
+        assert not self.sched.get("gelu_pk")
+        BQB = [V(8, 4), V(12, 4), V(16, 4), V(20, 4)]            # WF / XF: dead after the last k-step's prefetch reads
+        sets = [BQ, BQB]
+        self.lg_log = ["F"] * 7                                    # the (unused) prefetch fragment reads of a next tile's first k-step
+        nt = bool(self.sched.get("store_nt"))
+
+        def bias_reads(step, i):
+            for q in range(4):
+                p.ds_read_b128(sets[step % 2][q], VB, i * 128 + q * 32)
+                self.lg_log.append("b%d" % step)
+
+        def arithmetic(step, i, j):
+            B = SETB.sub(16 * (4 * i + j), 16)
+            bq = sets[step % 2]
+            for r in range(16):
+                p.v_accvgpr_read_b32(B[r], ACC[16 * (4 * i + j) + r])
+            for q in range(4):
+                for e in range(4):
+                    p.v_add_f32(B[4 * q + e], B[4 * q + e], bq[q][e])
+            if self.act == 1:
+                self.gelu_inline([B[k] for k in range(16)])
+            for q in range(4):
+                for d in range(2):
+                    p.v_cvt_pk_f16_f32(B[2 * q + d], B[4 * q + 2 * d], B[4 * q + 2 * d + 1])
+            for kp in range(2):
+                p.s_nop(1)                                # VALU write -> v_permlane32_swap: 2 wait states
+                for d in range(2):
+                    p.v_permlane32_swap_b32(B[4 * kp + d], B[4 * kp + 2 + d])
+            return B
+
+        if self.out_blocked:
+            # blocked-16 output: a store instruction is 1 KiB contiguous (no staging); W block outer (one bias set per W block), the two
+            # stores of an accumulator tile right behind its arithmetic
+            p.s_add_u32(T0, PO, T1)                         # T1: the wave's block offset (prologue)
+            bias_reads(0, 0)
+            for i in range(3):
+                if i + 1 < 3:
+                    bias_reads(i + 1, i + 1)
+                self.wait_tag("b%d" % i)
+                for j in range(4):
+                    B = arithmetic(i, i, j)
+                    for kp in range(2):
+                        p.s_mul_i32(T3, LDC32, j)           # row block j: 32 rows on
+                        p.s_add_u32(T3, T3, T0)
+                        p.s_add_u32(T2, T3, (2 * i + kp) * 1024)
+                        if not self.sched.get("no_store"):
+                            p.buffer_store_dwordx4(B.sub(4 * kp, 4), VS, RS_O, T2, nt=nt)
+                            self.vm_log.append("S")
+            return
+
+        ROWB, STG2 = 208, X_BASE + 2 * X_SLOT
+        EVR = [V(57), V(58), V(59), V(60), V(61), V(24)]          # read-back LDS address of lane + 64 r
+        EVG = [V(26), V(28), V(54), V(55), V(56), V(62)]          # ... and its global offset (VBD, VBL, VW, VX: dead)
+        lane, frow, fhalf, idx, row, seg, t = (GT[k] for k in range(7))
+        p.v_mbcnt_lane_id(lane)
+        p.v_and_b32(frow, 31, lane)
+        p.v_lshrrev_b32(fhalf, 5, lane)
+        p.s_lshl_b32(T0, WAVE, 13)
+        p.s_add_u32(T0, T0, STG2)                           # the wave's 8 KiB of X slot 2: 32 rows x 208 B
+        p.s_mov_b32(KBL, ROWB)                              # VOP3 takes no literal on gfx9: constants through (idle) SGPRs
+        p.v_mul_lo_u32(t, frow, KBL)
+        p.v_lshl_add_u32(t, fhalf, 4, t)
+        p.v_add_u32(VS, T0, t)                              # staging write address: row (lane & 31), 16-byte half (lane >> 5)
+        p.s_lshr_b32(T1, WAVE, 1)                           # wm
+        p.s_and_b32(T2, WAVE, 1)                            # wn
+        p.s_lshl_b32(T3, T1, 7)
+        p.s_mul_i32(T3, T3, LDC)
+        p.s_mul_i32(T2, T2, 192)
+        p.s_add_u32(T3, T3, T2)                             # wm * 128 rows + wn * 192 B
+        p.s_mov_b32(T1, 43691)
+        for r in range(6):
+            p.v_add_u32(idx, 64 * r, lane)
+            p.v_mul_lo_u32(row, idx, T1)
+            p.v_lshrrev_b32(row, 19, row)                   # idx // 12 (43691 / 2^19; exact for idx < 2^13)
+            p.v_mul_lo_u32(seg, row, 12)
+            p.v_sub_u32(seg, idx, seg)
+            p.v_lshlrev_b32(seg, 4, seg)                    # 16-byte segment of the 192-byte row
+            p.v_mul_lo_u32(t, row, KBL)
+            p.v_add_u32(t, t, seg)
+            p.v_add_u32(EVR[r], T0, t)
+            p.v_mul_lo_u32(t, row, LDC)
+            p.v_add_u32(t, t, seg)
+            p.v_add_u32(EVG[r], T3, t)
+
+        def quad(j, r):                                      # read-back r of row block j lands in the registers its data was written from
+            return SETB.sub(16 * (4 * (r // 2) + j) + 4 * (r % 2), 4)
+
+        def stores(j):
+            self.wait_tag("R%d" % j)
+            if j == 0:
+                p.s_mov_b32(T2, PO)
+            else:
+                p.s_add_u32(T2, T2, LDC32)                  # next row block: 32 rows on
+            for r in range(6):
+                if not self.sched.get("no_store"):
+                    p.buffer_store_dwordx4(quad(j, r), EVG[r], RS_O, T2, nt=nt)
+                    self.vm_log.append("S")
+
+        steps = [(j, i) for j in range(4) for i in range(3)]
+        bias_reads(0, 0)
+        for s_, (j, i) in enumerate(steps):
+            if s_ + 1 < len(steps):
+                bias_reads(s_ + 1, steps[s_ + 1][1])
+            self.wait_tag("b%d" % s_)
+            B = arithmetic(s_, i, j)
+            for kp in range(2):
+                p.ds_write_b128(VS, B.sub(4 * kp, 4), (2 * i + kp) * 32)
+                self.lg_log.append("w")
+            if i == 2:
+                for r in range(6):
+                    p.ds_read_b128(quad(j, r), EVR[r])
+                    self.lg_log.append("R%d" % j)
+            if i == 0 and j > 0:
+                stores(j - 1)                               # ... of the previous row block: its LDS round trip is long over
+        stores(3)
 
     # ------------------------------------------------------------------------------------------ one k-tile
     def ktile(self, kk, first, epi, drain=False):
@@ -717,6 +891,8 @@ class ZGen:
     def exposed_epilogue(self):
         if self.sched.get("no_epi"):
             return
+        if self.exposed_v2 and self.deferred:
+            return self.exposed_epilogue_v2()
         for _, _, fn in self.epi_atoms():
             fn()
 
@@ -749,11 +925,12 @@ class ZGen:
         p.label(tile_done)
         if self.deferred and not self.sched.get("burst_drain"):
             # a tile that is followed by another one is drained inside that tile's first k-step; only the last tile pays a burst
-            skip_burst = p.newlabel("noburst")
-            p.s_cmp_gt_u32(TLEFT, 1)
-            p.s_cbranch_scc1(skip_burst)
-            self.tile_end()
-            p.label(skip_burst)
+            if not (self.exposed_v2 and not self.sched.get("no_epi")):     # exposed_epilogue_v2 drains the last tile itself, 16 registers at a time
+                skip_burst = p.newlabel("noburst")
+                p.s_cmp_gt_u32(TLEFT, 1)
+                p.s_cbranch_scc1(skip_burst)
+                self.tile_end()
+                p.label(skip_burst)
         else:
             self.tile_end()
         # the finished tile's identity for its epilogue; then advance the tile bookkeeping
@@ -897,7 +1074,17 @@ def write_inc(path, prog):
 # (profiles/r04_z192_*.txt, r05_z192_*.txt) were edited here between runs; this is the last one.
 VARIANTS = {
     1: dict(deferred=True, sched=dict(no_epi=True), ablation=True),        # k-loops only
-    2: dict(deferred=True, sched=dict()),                                   # the product schedule (control: same code path as 70)
+    2: dict(deferred=True, sched=dict(gelu_deg=5, exposed_v2=False)),      # round 4's schedule (control)
+    3: dict(deferred=True, sched=dict(gelu_deg=4, exposed_v2=False)),      # GELU exponent polynomial of degree 4 (7 VALU per element)
+    4: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=False)),      # ... of degree 3 (6 VALU)
+    5: dict(deferred=True, sched=dict(gelu_deg=5, exposed_v2=True)),       # latency-ordered last-tile epilogue (exposed_epilogue_v2)
+    6: dict(deferred=True, sched=dict(gelu_deg=4, exposed_v2=True)),
+    7: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True)),
+    8: dict(deferred=True, sched=dict(gelu_deg=5, exposed_v2=False), out_blocked=True),     # the model's fc1 (blocked-16 hidden activation): control
+    9: dict(deferred=True, sched=dict(gelu_deg=4, exposed_v2=True), out_blocked=True),
+    10: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True), out_blocked=True),
+    11: dict(deferred=True, sched=dict(gelu_deg=5, exposed_v2=True, no_store=True), ablation=True),   # exposed_v2 without its global stores
+    12: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_nt=True)),        # non-temporal epilogue stores
 }
 
 PRODUCT_BODIES = {      # gemm_z192.hip includes gemm_z192_body_<name>.inc

@@ -45,7 +45,7 @@ __global__ void spoil_kernel(const float4* a, float4* b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { float4 v = a[i]; v.x += 1.f; b[i] = v; }
 }
 
-// blocked-16 layout helpers (GemmParams::a_blocked16 / out_blocked16): variants 77 (output blocked) and 78 (A operand blocked)
+// blocked-16 layout helpers (GemmParams::a_blocked16 / out_blocked16): variants 97 (product body, output blocked) and 98 (product body, A operand blocked)
 __global__ void to_blocked16(const f16* rm, f16* blk, int M, int N) {
     const size_t n = (size_t)M * N;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -113,9 +113,9 @@ int main(int argc, char** argv) {
             // variant 0 = what the library would do: split-K where its heuristic asks for it; 31 = 128x160 tiles with split-K 4
             if (variant == 0) { GemmParams t = g; t.variant = 0; const int sk = gemm_splitk_factor(t); if (sk > 1) { g.splitk = sk; g.split_ws = ws; } }
             if (variant == 31) { g.splitk = 4; g.split_ws = ws; }
-            if (variant == 77) { g.variant = 70; g.out_blocked16 = 1; }
+            if (variant == 97) { g.variant = 70; g.out_blocked16 = 1; }
             if (variant > 70 && variant <= 70 + z192_var_count() && z192_var_out_blocked(variant - 70) && s.act == 1) g.out_blocked16 = 1;
-            if (variant == 78) { g.variant = 70; g.a_blocked16 = 1; g.A = dA_blk; }
+            if (variant == 98) { g.variant = 70; g.a_blocked16 = 1; g.A = dA_blk; }
             return g;
         };
         std::vector<std::vector<float>> times(variants.size());

@@ -124,7 +124,7 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
     import torch.distributed as dist
     from sam_road_amd import _lib
     res = {}
-    for name, steps in (("full", 20), ("vith256", 20)):
+    for name, steps in (("full", 40), ("vith256", 40)):
         reuse = name == "full"                  # configs[2] is the headline's model with the TopoNet branch switched on
         net, _, _, step, B, P, WL = build_workload(name, 0, rank, dev, distributed, net=net_b if reuse else None, sd=sd_b if reuse else None)
 
@@ -133,7 +133,7 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize(dev)
-        for _ in range(3):
+        for _ in range(5):
             step()
         sync_all()
         t0 = time.perf_counter()
@@ -148,7 +148,7 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
         assert all(torch.isfinite(x).all() for x in o)
         tps = world * B * steps / el
         r = {"config": f"{WL['yaml']}, batch={B} {P}x{P} tiles per GPU, {WL['what']}", "tiles_per_s": round(tps, 2),
-             "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": 3, "n_gpus": world, "dtype": "f16",
+             "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": 5, "n_gpus": world, "dtype": "f16",
              "gflop_per_tile_algorithmic": WL["gflop"],
              "whole_path_mfma_frac": round(tps / world * WL["gflop"] / 1e3 / MFMA_PEAK_TFLOPS, 4)}
         if rank == 0:

@@ -6,8 +6,9 @@
 What is minimised is max_a |a 2^-r(a) - a Phi(-a)|, the absolute error of the GELU output itself.  The table also gives the error
 AFTER the result is rounded to fp16 (what the hidden activation is stored as), next to the exact function rounded to fp16, and the
 same for the polynomial evaluated in PACKED fp16 (v_pk_fma_f16 on the already-converted operand — the form the round-4 verdict asked
-to be measured): degree 4 in f32 is indistinguishable from exact-then-rounded (it is what gemm_z192 ships since round 5: 7 VALU per
-element instead of 8); degree 3 adds 1.8 % to the rms rounding error; packed fp16 adds 50 % and is not used.
+to be measured): degree 3 in f32 — what gemm_z192 ships since round 5, 6 VALU per element instead of 8 — adds 1.8 % to the rms error of
+exact-then-rounded; degree 4 is indistinguishable from exact-then-rounded but its optimum has a negative leading coefficient and
+overflows beyond |x| ~ 18 (unusable without a clamp, which costs the instruction it saves); packed fp16 adds 50 % and is not used.
 Reference: nn.GELU() (exact erf) in the SAM fork's MLPBlock, reached through /root/reference/model.py:245-258."""
 import sys
 

@@ -82,15 +82,19 @@ KARG_BYTES = 96
 
 # exact-erf GELU as  max(x, 0) - |x| 2^(-r(|x|)),  r a polynomial fitted (tools/fit_gelu.py) so that max_a |a 2^-r(a) - a Phi(-a)| is
 # as small as the degree allows.  Highest power first; the last entry is the constant term (1.0 exactly for the round-1 degree-5 fit).
-#   degree 5: 1.6e-6   degree 4: 1.1e-5   degree 3: 9.5e-5   (absolute, over all a >= 0; an fp16 half-ulp is 6.1e-5 at 0.125 <= |y| < 0.25
-#   and 2.4e-4 at 0.5 <= |y| < 1: tools/fit_gelu.py prints the rounded-output error of each degree)
+#   degree 5: 1.6e-6   degree 4: 1.1e-5   degree 3: 9.5e-5   (absolute; an fp16 half-ulp is 6.1e-5 at 0.125 <= |y| < 0.25 and 2.4e-4 at
+#   0.5 <= |y| < 1: tools/fit_gelu.py prints the rounded-output error of each degree)
+# ONLY degrees 3 and 5 are safe for every input: their leading coefficient is positive, r grows without bound and 2^-r underflows to 0.
+# The degree-4 optimum has a NEGATIVE leading coefficient: r(a) turns negative at |x| ~ 18, 2^-r overflows and the output is inf / NaN —
+# found by the heavy-tailed-weights GPU test in round 5 (fc1 pre-activations beyond 18 exist with outlier channels); it stays here for
+# the probe variants only, and tests/test_kgen_emulator.py asserts that the shipped degree is finite over the whole fp16 range.
 GELU_FITS = {
     5: [0.00048291164585022967, -0.0071898452371611365, 0.05218537922649359, 0.4595148493607732, 1.1510354141727006, 1.0],
     4: [-0.004179672357674636, 0.045596776558867104, 0.46561372080778884, 1.1487885005872824, 1.0002332302268748],
     3: [0.027115101429684235, 0.49156223219618944, 1.135889844701584, 1.001923220905336],
 }
 EXPOSED_V2 = True       # the product bodies' exposed (last-tile) epilogue: False = the deferred atoms back to back, True = exposed_epilogue_v2
-GELU_DEG = 4            # the product bodies' degree (PRODUCT_BODIES may override per body)
+GELU_DEG = 3            # the product bodies' degree (PRODUCT_BODIES may override per body)
 GELU_C = GELU_FITS[5]
 
 

@@ -52,9 +52,11 @@ int main(int argc, char** argv) {
     AttnParams p;
     p.qkv = dq; p.ld = 3 * D; p.table_h = dh; p.table_w = dw; p.bias_qkv = db; p.ldo = D; p.B = B; p.S = S; p.heads = heads; p.hd = 64; p.win = 14;
     p.scale = 0.125f;
-    // outputs: with and without the key split
-    p.out = o0; p.ablate = 5; if (launch_attention(p, st)) { printf("launch failed\n"); return 1; }
-    p.out = o1; p.ablate = 0; if (launch_attention(p, st)) { printf("launch failed\n"); return 1; }
+    void* scratch; CK(hipMalloc(&scratch, ATTN_SCRATCH_BYTES + 256 * 8 * 8 * 8)); CK(hipMemset(scratch, 0, ATTN_SCRATCH_BYTES + 256 * 8 * 8 * 8));
+    p.scratch = scratch;
+    // outputs: the shipped one-workgroup-per-window kernel (ablate 0) against the persistent experiment (ablate 40)
+    p.out = o0; p.ablate = 0; if (launch_attention(p, st)) { printf("launch failed\n"); return 1; }
+    p.out = o1; p.ablate = 40; if (launch_attention(p, st)) { printf("launch failed\n"); return 1; }
     CK(hipStreamSynchronize(st));
     std::vector<f16> h0(T * D), h1(T * D);
     CK(hipMemcpy(h0.data(), o0, T * D * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o1, T * D * 2, hipMemcpyDeviceToHost));
@@ -63,7 +65,7 @@ int main(int argc, char** argv) {
         const int y = (t / S) % S, x = t % S;
         const int wy = y / 14, wx = x / 14;
         const int nry = std::min(14, S - wy * 14), nrx = std::min(14, S - wx * 14);
-        const int cls = (nry * nrx > 64) ? 0 : (nry * nrx > 32 ? 1 : 2);
+        const int cls = (nry * nrx > 128) ? 0 : (nry * nrx > 64 ? 1 : 2);
         for (int d = 0; d < D; ++d) {
             const float a = (float)h0[t * D + d], b = (float)h1[t * D + d];
             if (std::isnan(b)) ++nanc;
@@ -72,14 +74,38 @@ int main(int argc, char** argv) {
         }
     }
     printf("B=%d S=%d  max|out|=%.3f  NaN=%zu\n", B, S, ref_max, nanc);
-    const char* names[3] = {"full (>2 query tiles)", "edge (2 query tiles)", "corner (1 query tile)"};
-    for (int c = 0; c < 3; ++c) printf("  %-24s max |split - unsplit| = %.3e   values differing %zu of %zu\n", names[c], md[c], nd_[c], nn[c]);
+    const char* names[3] = {"5-7 query tiles (same split)", "3-4 query tiles (split here)", "1-2 query tiles (split in both)"};
+    for (int c = 0; c < 3; ++c) printf("  %-32s max |persistent - per-window| = %.3e   values differing %zu of %zu\n", names[c], md[c], nd_[c], nn[c]);
     p.out = o1;
-    for (int rep = 0; rep < 2; ++rep)
-        printf("  windowed:  full %6.1f us   no key loop %6.1f   no staging %6.1f   no rel-pos %6.1f   no key split %6.1f   launch floor %6.1f\n",
-               run(p, 0, 10, st), run(p, 1, 10, st), run(p, 2, 10, st), run(p, 3, 10, st), run(p, 5, 10, st), run(p, 7, 10, st));
-    { const float t0_ = run(p, 0, 10, st), t8_ = run(p, 8, 10, st);
-      printf("  windowed:  key loops x 4 %6.1f us -> the key loops alone cost %6.1f us of %6.1f\n", t8_, (t8_ - t0_) / 3, t0_); }
+    for (int rep = 0; rep < 3; ++rep)
+        printf("  windowed:  per-window kernel, heavy-first order %6.1f us   round-4 order %6.1f   persistent %6.1f   persistent: no key loop %6.1f   no rel-pos %6.1f   |  per-window: no key loop %6.1f   no staging %6.1f   no rel-pos %6.1f\n",
+               run(p, 0, 10, st), run(p, 4, 10, st), run(p, 40, 10, st), run(p, 41, 10, st), run(p, 43, 10, st), run(p, 1, 10, st), run(p, 2, 10, st), run(p, 3, 10, st));
+    {   // phase ticks of the persistent experiment (ablate 49): per wave of every workgroup, averaged over the workgroups
+        p.ablate = 49; launch_attention(p, st); CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hd(256 * 8 * 8);
+        CK(hipMemcpy(hd.data(), (char*)scratch + ATTN_SCRATCH_BYTES, hd.size() * 8, hipMemcpyDeviceToHost));
+        const char* ph[8] = {"tail(stores,ctl)", "own DMA wait", "barrier wait", "setup+relpos", "decode+issue+qload", "key loops", "merge", "exit"};
+        for (int w = 0; w < 8; w += 7) {
+            printf("  persistent kernel, wave %d, ticks per workgroup (avg over workgroups):", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { double a = 0; int nz = 0; for (int b = 0; b < 256; ++b) { a += (double)hd[(b * 8 + w) * 8 + k]; nz += hd[(b * 8 + w) * 8 + k] != 0; } a /= 256; tot += a; printf("  %s %.0f", ph[k], a); }
+            printf("  | total %.0f\n", tot);
+        }
+        // the per-window kernel (ablate 9 = its phase counters): sums over the workgroups that share a counter row (blockIdx & 255), i.e.
+        // about the same 6.75 workgroups as one persistent workgroup's items
+        CK(hipMemset((char*)scratch + ATTN_SCRATCH_BYTES, 0, 256 * 8 * 8 * 8));
+        p.ablate = 9; launch_attention(p, st); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(hd.data(), (char*)scratch + ATTN_SCRATCH_BYTES, hd.size() * 8, hipMemcpyDeviceToHost));
+        const char* pk[8] = {"decode+issue+qload", "own DMA wait", "barrier", "setup+relpos", "key loops", "stores", "merge+stores", "-"};
+        for (int w = 0; w < 4; w += 3) {
+            printf("  per-window kernel, wave %d, ticks per 6.75 workgroups (avg):", w);
+            double tot = 0;
+            for (int k = 0; k < 7; ++k) { double a = 0; for (int b = 0; b < 256; ++b) a += (double)hd[(b * 8 + w) * 8 + k]; a /= 256; tot += a; printf("  %s %.0f", pk[k], a); }
+            printf("  | total %.0f\n", tot);
+        }
+        p.ablate = 0;
+    }
+    if (argc > 3) return 0;         // windowed only
     AttnParams g = p; g.win = S;
     {   // global attention: the generated-asm kernel (attention_g64.hip) against the HIP kernel (ablate 9), bit for bit
         CK(hipMemset(o0, 0, T * D * 2)); CK(hipMemset(o1, 0xff, T * D * 2));

@@ -390,6 +390,123 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// gemm_r8_kernel (round 5) — the small-M layers of ViT-H / ViT-L at 256 px again (M = 2048 rows): 128(M) x 256(N) x 64 tiles, EIGHT waves
+// (2 x 4 wave tiles of 64 x 64: two waves per SIMD), a three-stage ring of 48 KiB stages (one workgroup per CU), LDS-DMA two k-tiles
+// ahead.  Against gemm_ring_kernel: twice the MFMA work per k-tile and per barrier on the same DMA latency, and ViT-H's qkv (480 tiles of
+// 128 x 128 = two workgroups on every CU with one k-tile of lookahead each) becomes 240 tiles = one round.  What it is bound by: the rate at
+// which a CU's address path takes LDS-DMA pieces (a 128 x 256 k-tile is 48 KiB for 1024 clk of MFMA per SIMD; the path sustains ~34 B/clk:
+// ~1450 clk), measured 1.1 us per k-tile on 240 CUs against 0.72 on 80 — small-M tiles move too many operand bytes per FLOP through it.
+// The LDS-DMA is issued from INLINE ASM and waited for with an inline-asm counted s_waitcnt (the form found for the persistent attention
+// experiment, attention.hip): the compiler does not know that LDS-DMA is in flight, so the ring needs neither one static LDS object per
+// stage nor an unrolled stage sequence — the stage is a runtime offset into one dynamic LDS block — and no conservative vmcnt(0) appears
+// before LDS reads.  What that leaves to this code (checked by tests/test_isa_contract.py on the emitted ISA: exactly 6 LDS-DMA and no
+// other VMEM operation per k-tile and wave): RAW — k-tile kt is read behind "s_waitcnt vmcnt(6); s_barrier" (6 = the pieces of k-tile
+// kt + 1, the only younger operations); WAR — the DMA of k-tile kt + 2 goes into the stage of k-tile kt - 1 and is issued behind that
+// barrier, which every wave passes only after its last fragment read of k-tile kt - 1 has been consumed by an MFMA.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, unsigned lds_wave_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_wave_uniform) : "memory");
+}
+
+constexpr int R8_BM = 128, R8_BN = 256, R8_XT = R8_BM * BK * 2, R8_WT = R8_BN * BK * 2, R8_STAGE = R8_XT + R8_WT, R8_NST = 3;
+constexpr int R8_LDS = R8_NST * R8_STAGE;          // 147 456 B
+
+__global__ __launch_bounds__(512, 1) void gemm_r8_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + R8_BM - 1) / R8_BM, p.N / R8_BN, tile_m, tile_n);
+    const int m0 = tile_m * R8_BM, n0 = tile_n * R8_BN;
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, zsplit = blockIdx.y;
+    const int kt0 = zsplit * (p.K / BK) / nsplit, nk = (zsplit + 1) * (p.K / BK) / nsplit;
+
+    // DMA pieces of a k-tile: 8 rows x 128 B each (1 KiB), swizzle on the source side.  X has 16 (wave w: pieces w, w + 8), W has 32
+    // (wave w: pieces w, w + 8, w + 16, w + 24): 6 per wave.  Per-lane 32-bit offsets against the scalar bases A + kt*128, W + kt*128.
+    const int prow = lane >> 3, pc = lane & 7;
+    unsigned xoff[2], woff[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + prow;
+        xoff[i] = (unsigned)((min(m0 + r, p.M - 1) * p.lda + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i * 8 + wave) * 8 + prow;
+        woff[i] = (unsigned)(((n0 + r) * p.ldw + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+    const char* const abase = reinterpret_cast<const char*>(p.A);
+    const char* const wbase = reinterpret_cast<const char*>(p.W);
+    const int klast = nk - 1;
+    auto dma_ktile = [&](int kt, int stage) {
+        const char* a = abase + (size_t)kt * (BK * 2);
+        const char* w = wbase + (size_t)kt * (BK * 2);
+        const unsigned d = lds0 + stage * R8_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16_saddr(xoff[i], a, d + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16_saddr(woff[i], w, d + R8_XT + i * 8192);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * 64) * 128, x_row0 = (wm * 64) * 128;
+
+    dma_ktile(min(kt0, klast), 0);
+    dma_ktile(min(kt0 + 1, klast), 1);
+    int stage = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // k-tile kt has landed (this wave's pieces); k-tile kt + 1 may stay in flight
+        __syncthreads();                                     // ... every wave's pieces; and every wave is done with k-tile kt - 1's stage
+        const int nxt = stage == 0 ? R8_NST - 1 : stage - 1; // (stage + NST - 1) % NST: the stage k-tile kt - 1 used
+        dma_ktile(min(kt + R8_NST - 1, klast), nxt);         // the tail re-fetches the last k-tile: the counts above stay exact
+        // (issuing the six pieces two at a time behind the first three MFMA groups instead measured the same: the k-tile is bound by the
+        // rate at which the CU's address path accepts LDS-DMA pieces, not by where the wave issues them — profiles/r05_vith_gemm_r8.txt)
+        const char* sa = smem + stage * R8_STAGE + x_row0;
+        const char* sw = smem + stage * R8_STAGE + R8_XT + w_row0;
+        f16x8 fwA[2], fxA[2], fwB[2], fxB[2];
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG2(fwA, fxA, 0)
+        SRH_FRAG2(fwB, fxB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA2(fwA, fxA)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG2(fwA, fxA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA2(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG2(fwB, fxB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA2(fwA, fxA)
+        SRH_MMA2(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage == R8_NST - 1 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail's redundant fetches have landed
+    __syncthreads();                                         // every wave is done reading operand tiles: the ring becomes epilogue staging space
+    if (nsplit > 1) {  // raw f32 partial sums; bias / residual / activation are applied by splitk_reduce_kernel
+        GemmParams q = p;
+        q.bias = nullptr; q.resid = nullptr; q.pos = nullptr; q.act = 0; q.out_f16 = nullptr;
+        q.out_f32 = p.split_ws + (size_t)zsplit * p.M * p.N; q.ldc = p.N;
+        epilogue_staged<2, 0>(q, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+        return;
+    }
+    epilogue_staged<2, 0>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 128(M) x 160(N) x 64 LDS-DMA variant for the SMALL-M layers whose 128x128 tile count misses the chip's 512 workgroup slots
 // (two workgroups per CU): ViT-H at 256 px, B = 8 has M = 2048 rows, and fc1 (N = 5120) is 640 tiles of 128x128 = two rounds
 // with the second a quarter full, but exactly 512 tiles of 128x160 = ONE round.  Four waves stacked along M: wave tile 32(M) x 160(N) = 1 x 5 v_mfma_f32_32x32x16_f16 tiles (80
@@ -716,8 +833,23 @@ static bool use_tile160(const GemmParams& p) {
     return t128 > 512 && t160 <= 512;
 }
 
+// gemm_r8_kernel's share of the small-M layers: those that are ONE round of 128 x 256 tiles with at least ~5/8 of the CUs busy (ViT-H qkv:
+// 240 tiles, 28.7 -> 26.5 us; ViT-L qkv / fc1).  With split-K for the few-tile layers (ViT-H proj / fc2: 80 tiles x 3 slices) it measured
+// WORSE than the 128 x 128 kernels (proj 26.8 vs 18.9 us, fc2 45.6 vs 46.3, profiles/r05_vith_gemm_r8.txt): the kernel keeps the split-K
+// code path (probe variant 45) but the dispatch does not use it.
+static bool r8_applies(const GemmParams& p) {
+#ifdef SRH_TUNING      // probe builds: A/B switch
+    static const bool on = !(getenv("SRH_GEMM_R8") && atoi(getenv("SRH_GEMM_R8")) == 0);
+    if (!on) return false;
+#endif
+    if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % R8_BN != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p)) return false;
+    const long tiles = (long)((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN);
+    return tiles >= 160 && tiles <= 256;
+}
+
 // Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
 int gemm_splitk_factor(const GemmParams& p) {
+    if (r8_applies(p)) return 1;
     if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
     if (p.M >= 4096 || z192_preferred(p)) return 1;
     if (use_tile160(p)) return 1;
@@ -766,6 +898,11 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
             *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
             return true;
         }
+        case 45:                                   // the 8-wave ring kernel with the caller's split-K
+            if (p.N % R8_BN != 0) return true;
+            hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), sk), dim3(512), R8_LDS, stream, p);
+            *rc = sk > 1 ? launch_splitk_reduce(p, stream) : launched();
+            return true;
         case 40: case 41:                          // the ring kernel, 4 / 3 stages, with the caller's split-K
             if (variant == 40) hipLaunchKernelGGL((gemm_ring_kernel<4>), dim3(grid, sk), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid, sk), dim3(256), 0, stream, p);
@@ -782,7 +919,8 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
 //   3x3 conv (neck)                                     -> register-staged implicit GEMM
 //   big fp16-output layers with a bias (ViT-B blocks)   -> gemm_z192 (generated body, persistent 256 x 192 tiles, deferred epilogue)
 //   M >= 4096, N % 256 == 0, tiles fill the chip        -> 256 x 256 LDS-DMA tiles
-//   small M (ViT-L / ViT-H at 256 px)                   -> 128 x 160 tiles | 128 x 128 split-K + ordered reduce | 3-stage ring
+//   small M (ViT-L / ViT-H at 256 px)                   -> 128 x 256 tiles on the 8-wave ring kernel (+ split-K) | 128 x 160 tiles | 128 x 128
+//                                                          split-K + ordered reduce | 3-stage ring
 //   everything else                                     -> 128 x 128 LDS-DMA tiles, two workgroups per CU
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
@@ -803,7 +941,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (!opt_in.run([] {
             const std::pair<const void*, int> k[] = {
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds160_kernel), 73728},
-                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072},
+                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072}, {reinterpret_cast<const void*>(gemm_r8_kernel), R8_LDS},
 #ifdef SRH_TUNING
                 {reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), 65536},
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), 65536}, {reinterpret_cast<const void*>(gemm_glds256_kernel<1>), 131072},
@@ -823,6 +961,12 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
     if (p.N % 256 == 0 && p.M >= 4096 && p.K > 256 && fits256) {
         hipLaunchKernelGGL(gemm_glds256_kernel<0>, dim3((unsigned)t256), dim3(512), 131072, stream, p);
+        return launched();
+    }
+    if (r8_applies(p)) {                          // small-M layers in one round of 128 x 256 tiles on the 8-wave ring kernel
+        GemmParams q = p;
+        q.splitk = 1;
+        hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), 1), dim3(512), R8_LDS, stream, q);
         return launched();
     }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);

@@ -82,3 +82,49 @@ def test_global_attention_ring_has_one_wait_per_stage():
                 assert nxt[:upto][len(nxt[:upto]) - after_reads:] == [0] or 0 in nxt[:upto][-after_reads - 1:], nxt[:upto]
             stages += 1
     assert stages >= 2, ev
+
+
+def _vmem_events(body):
+    """Every VMEM operation and vmcnt wait of a kernel body, in program order: 'D' LDS-DMA, 'L' load, 'S' store, int = vmcnt(n), 'B' barrier."""
+    ev = []
+    for ln in body.split("\n"):
+        t = ln.split(";")[0].strip()
+        if t.startswith("s_barrier"):
+            ev.append("B")
+        elif re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t):
+            ev.append(int(re.search(r"vmcnt\((\d+)\)", t).group(1)))
+        elif re.match(r"(buffer_load\w* .* lds|global_load_lds)", t):
+            ev.append("D")
+        elif re.match(r"(global|buffer|flat|scratch)_load", t):
+            ev.append("L")
+        elif re.match(r"(global|buffer|flat|scratch)_store", t):
+            ev.append("S")
+    return ev
+
+
+def test_gemm_r8_ring_counts_are_what_the_source_assumes():
+    """gemm_r8_kernel issues its LDS-DMA from inline asm and waits with an inline-asm vmcnt(6): the compiler knows nothing about either,
+    so the count is only right if a wave's k-loop contains exactly 6 LDS-DMA operations per trip and NO other VMEM operation (a spill, a
+    hoisted load) — checked on the ISA hipcc emits.  Prologue: two k-tiles = 12 pieces before the loop."""
+    isa = _isa("gemm.hip")
+    body = _kernel_body(isa, "gemm_r8_kernel")
+    assert "scratch_" not in body, "gemm_r8_kernel spills: the vmcnt(6) of its ring is no longer exact"
+    ev = _vmem_events(body)
+    i = ev.index(6)                                          # the loop's counted wait
+    assert ev[:i].count("D") == 12 and "L" not in ev[:i] and "S" not in ev[:i], ev[:i]
+    assert ev[i + 1] == "B", ev[i:i + 3]
+    j = i + 2
+    trip = []
+    while j < len(ev) and ev[j] != 0:                        # up to the tail's vmcnt(0)
+        trip.append(ev[j])
+        j += 1
+    assert trip == ["D"] * 6, f"one k-tile of the ring must be exactly 6 LDS-DMA operations, got {trip}"
+    assert ev[j] == 0 and ev[j + 1] == "B", ev[j:j + 3]
+
+
+def test_attention_output_stores_are_16_bytes():
+    """store_query: one v_permlane32_swap per pair of register quads, then 4 stores of 16 bytes per lane (was 8 of 8 bytes) — the store
+    path's cost is per instruction (32 token rows each either way)."""
+    body = _kernel_body(_isa("attention.hip", ["-fno-honor-nans"]), "attn_window_kernel")
+    assert len(re.findall(r"global_store_dwordx4", body)) >= 4 and not re.findall(r"global_store_dwordx2", body)
+    assert len(re.findall(r"v_permlane32_swap", body)) >= 8

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 6
+#define SRH_ABI_VERSION 7
 
 typedef enum {
     SRH_OK = 0,
@@ -107,6 +107,15 @@ int srh_encode_decode(srh_ctx* ctx, const srh_weights* w, const void* rgb, int r
 int srh_toponet(srh_ctx* ctx, const srh_weights* w, const float* embeddings, const void* points,
                 int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
                 int Ns, int K, float* logits, float* scores, void* stream);
+
+/* infer_toponet over the query rows of MANY tiles at once, unpadded (pass 2 of infer_one_img, inferencer.py:179-207: the reference
+ * pads every batch of INFER_BATCH_SIZE tiles to its longest tile, graph_collate_fn-style; every row is scored on its own, so the
+ * padding rows are pure waste — 68 k padded rows for 48 k real ones on a CityScale scene).  Rows = the concatenated per-tile point
+ * lists; points f32 [R,2] tile-local (x,y); point_tile i32 [R] = index of the row's tile in `embeddings` [n,h,w,256]; pairs i32
+ * [R,K,2] = (row, target row) into the flat list; valid u8 [R,K]; scores f32 [R,K] out.  srh_pass2_pack_ragged builds these. */
+int srh_toponet_ragged(srh_ctx* ctx, const srh_weights* w, const float* embeddings, const float* points,
+                       const int32_t* point_tile, const int32_t* pairs, const uint8_t* valid, int64_t R, int K,
+                       float* scores, void* stream);
 
 /* scene level (pass 1 of infer_one_img, inferencer.py:79-110) ------------------------------------ */
 
@@ -232,6 +241,10 @@ int srh_pass2_votes(const float* scores, int32_t nb, int64_t n_max, int32_t K, c
  * [nb,n_max,K,2] (source row, target row — the source itself where invalid) and valid u8 [nb,n_max,K], zero beyond a tile's rows. */
 int srh_pass2_pack(const int64_t* offsets, const int64_t* local, const int32_t* knn, int32_t nb, int64_t n_max, int32_t K,
                    float* points, int32_t* pairs, uint8_t* valid);
+/* The unpadded collate for srh_toponet_ragged: rows keep their position in the flat query arrays (numbered from offsets[0]), pairs
+ * index the flat list, point_tile[r] = the row's tile counted from the first tile of the range. */
+int srh_pass2_pack_ragged(const int64_t* offsets, const int64_t* local, const int32_t* knn, int32_t n_tiles, int32_t K,
+                          float* points, int32_t* pairs, uint8_t* valid, int32_t* point_tile);
 
 /* Directed edge votes of pass 2 (reference inferencer.py:209-221: dict of score sums / counts keyed by (src, tgt), filled in
  * tile / point / slot order).  keys[i] = src * n_points + tgt, scores[i] in that visiting order.  Writes the unique keys in

@@ -867,9 +867,9 @@ extern "C" int srh_encode_decode(srh_ctx* c, const srh_weights* w, const void* r
 }
 
 // ---- TopoNet --------------------------------------------------------------------------------------------
-extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embeddings, const void* points,
-                           int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
-                           int Ns, int K, float* logits, float* scores, void* stream) {
+static int toponet_impl(srh_ctx* c, const srh_weights* w, const float* embeddings, const void* points,
+                        int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
+                        int Ns, int K, float* logits, float* scores, const int* point_tile, void* stream) {
     if (!c || !w || !embeddings || !points || !pairs || !valid) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet: null argument");
     if (B <= 0 || N < 0 || Ns < 0) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet: bad sizes");
     if (K != 16) return fail(c, SRH_ERR_UNSUPPORTED, "n_pairs must be 16 (MAX_NEIGHBOR_QUERIES)");
@@ -888,6 +888,7 @@ extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embedd
     SampleParams sp;
     sp.emb = embeddings; sp.points = points; sp.points_i64 = points_dtype == SRH_I64; sp.B = B; sp.N = N;
     sp.h = w->S; sp.w = w->S; sp.C = 256; sp.patch = (float)w->cfg.patch_size; sp.out_f16 = c->t_feat16.as<f16>();
+    sp.point_tile = point_tile;
     TRYK(c, "bilinear_sample", 0, (double)NP * 256 * 18, s, launch_sample(sp, s));
     GemmParams g;
     g.A = c->t_feat16.as<f16>(); g.lda = 256; g.W = w->tp_feat_w; g.ldw = 256; g.M = (int)NP; g.N = 128; g.K = 256;
@@ -907,6 +908,23 @@ extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embedd
         TRYK(c, "topo_fused", fl, 0, s, launch_topo_fused(tf, s));
         return 0;
     }
+}
+
+extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embeddings, const void* points,
+                           int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
+                           int Ns, int K, float* logits, float* scores, void* stream) {
+    return toponet_impl(c, w, embeddings, points, points_dtype, pairs, pairs_dtype, valid, B, N, Ns, K, logits, scores, nullptr, stream);
+}
+
+// The query rows of MANY tiles in one call, without padding every tile to the longest one of its batch: rows are the concatenated
+// per-tile point lists (srh_pass2_pack_ragged), every point names the tile whose embeddings it samples, pairs index the flat list.
+// The sampler, feature_proj, pair gather and the fused trunk treat every row on its own, so the scores are those of srh_toponet.
+extern "C" int srh_toponet_ragged(srh_ctx* c, const srh_weights* w, const float* embeddings, const float* points,
+                                  const int32_t* point_tile, const int32_t* pairs, const uint8_t* valid, int64_t R, int K,
+                                  float* scores, void* stream) {
+    if (!point_tile) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: null argument");
+    if (R < 0 || R * (int64_t)K > 0x7fffffffLL / 2) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: bad row count");
+    return toponet_impl(c, w, embeddings, points, SRH_F32, pairs, SRH_I32, valid, 1, (int)R, (int)R, K, nullptr, scores, point_tile, stream);
 }
 
 // ---- scene level ------------------------------------------------------------------------------------------

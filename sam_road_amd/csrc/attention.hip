@@ -156,30 +156,29 @@ __device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size
 // floats).  The w table goes first: its 16 per-lane values (tile-invariant) are read back into st.relw, then the same
 // buffer is overwritten with the h table, which the key loop reads one or two scalars per tile.
 template <int WIN, int STRIDE>
-__device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, int qy, int qx, float* buf, int lane) {
+__device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, int qy, int qx, float* buf, const char* tbl_lds, int lane) {
     constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
     static_assert(STRIDE > WIN, "slot WIN of a row is the dump slot");
     const int half = lane >> 5, row = lane & 31;
     const float inv_scale = 1.0f / p.scale;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {            // 0: w table -> st.relw, 1: h table -> buf
-        const f16* table = pass == 0 ? p.table_w : p.table_h;
         const int qc = pass == 0 ? qx : qy;
 #pragma unroll
         for (int jt = 0; jt < NTJ; ++jt) {
-            const int j = jt * 32 + row;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // A operand: table rows j = 32 jt + (lane & 31), staged in LDS in the K-tile format (tile pass * NTJ + jt; rows past the table's
+            // end hold a copy of its last row: their products land in the dump slot).  They used to be read straight from L2 — sixteen
+            // 16-byte loads per lane that touch 32 table rows each, ~87 ticks of the CU's address path per instruction; the staged form
+            // costs the workgroup 2 NTJ x 4 LDS-DMA pieces in all (profiles/r05_attention_global.txt)
+            f16x8 a[4];
+            read_kfrag(a, tbl_lds + (pass * NTJ + jt) * 4096, lane);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                f16x8 a;
-                if (j < 2 * WIN - 1) a = *reinterpret_cast<const f16x8*>(table + (size_t)j * HD + (ks * 2 + half) * 8);
-                else for (int e = 0; e < 8; ++e) a[e] = (f16)0.f;
-                acc = mfma32(a, st.q[ks], acc);
-            }
+            for (int ks = 0; ks < 4; ++ks) acc = mfma32(a[ks], st.q[ks], acc);
             // P^T[j, q] -> rel[q][k = qc - j + WIN - 1]: one subtract, one unsigned min and an unconditional write per element (k < 0
-            // and k >= WIN — also the zero rows j > 2 WIN - 2 — land in the dump slot WIN) instead of two compares and an exec-masked write
+            // and k >= WIN — also the rows j > 2 WIN - 2 — land in the dump slot WIN) instead of two compares and an exec-masked write
             const unsigned kb = (unsigned)(qc + WIN - 1 - jt * 32 - 4 * half);
             float* rowp = buf + row * STRIDE;
 #pragma unroll
@@ -869,6 +868,18 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 4096), 16, ko, so_ + 32 * ldb, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 8192), 16, vo, so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 12288), 16, vo, so_ + 32 * ldb, 0, 0); }
+    {   // the two rel-pos tables into ring1 in the K-tile format (2 NTJ tiles of 4 KiB: ring1 is exactly that big for the 32 x 32 window; K / V
+        // stage 1 overwrites it behind stage 0's barrier, which every wave passes after its rel-pos): wave w moves rows 8 w .. 8 w + 7 of a tile
+        constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
+        static_assert(2 * NTJ * 4096 <= STAGE, "the tables are staged in one ring stage");
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+#pragma unroll
+        for (int tt = 0; tt < 2 * NTJ; ++tt) {
+            const int j = min((tt % NTJ) * 32 + r, 2 * WIN - 2);
+            const f16* src = (tt < NTJ ? p.table_w : p.table_h) + (size_t)j * HD + (cpos ^ ((r >> 1) & 7)) * 8;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(ring1 + tt * 4096 + wave * 1024), 16, 0, 0);
+        }
+    }
     SRH_DMA_STAGE(0, ring0)                                        // in flight under the query loads and the rel-pos prologue
 
     const int qi = qb * 128 + wave * 32 + (lane & 31);
@@ -876,7 +887,10 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
     QState st;
     load_query<WIN>(st, p, tok, head, lane);
     float* rh = rh_lds + wave * 32 * (WP + 1);
-    fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F74);                            // vmcnt(4): the table pieces have landed (stage 0's four may stay in flight) ...
+    __builtin_amdgcn_s_barrier();                                  // ... every wave's
+    asm volatile("" ::: "memory");
+    fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, ring1, lane);
     int vb0, vb1;
     vtr_bases(lane, vb0, vb1);
 

@@ -681,6 +681,35 @@ extern "C" int srh_pass2_pack(const int64_t* offsets, const int64_t* local, cons
     return 0;
 } catch (...) { return SRH_ERR_HIP; }      // std::bad_alloc / std::system_error (thread limit) must not cross the C ABI
 
+// The same collate WITHOUT padding (srh_toponet_ragged): the flat query arrays are already the concatenation of the tiles' point lists,
+// so a row keeps its position; pairs become indices into the flat list (offsets[t] + tile-local index) and every row names its tile.
+//   points f32 [R, 2], pairs i32 [R, K, 2], valid u8 [R, K], point_tile i32 [R]  with R = offsets[n_tiles] - offsets[0]; rows are
+//   numbered from offsets[0] (the first tile of the range); tile numbers in point_tile count from 0 at that tile.
+extern "C" int srh_pass2_pack_ragged(const int64_t* offsets, const int64_t* local, const int32_t* knn, int32_t n_tiles, int32_t K,
+                                     float* points, int32_t* pairs, uint8_t* valid, int32_t* point_tile) try {
+    if (!offsets || !local || !knn || !points || !pairs || !valid || !point_tile || n_tiles < 0 || K <= 0) return SRH_ERR_BAD_ARG;
+    const int64_t base = offsets[0];
+    for (int32_t t = 0; t < n_tiles; ++t) {
+        const int64_t a = offsets[t], n = offsets[t + 1] - a;
+        if (n < 0) return SRH_ERR_BAD_ARG;
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t g = a + r - base;                       // row in the outputs
+            points[2 * g] = (float)local[2 * (a + r)];
+            points[2 * g + 1] = (float)local[2 * (a + r) + 1];
+            point_tile[g] = t;
+            const int32_t* row = knn + (a + r) * K;
+            for (int32_t j = 0; j < K; ++j) {
+                const bool ok = row[j] >= 0;
+                if (ok && row[j] >= n) return SRH_ERR_BAD_ARG;
+                valid[g * K + j] = ok ? 1 : 0;
+                pairs[(g * K + j) * 2] = (int32_t)g;
+                pairs[(g * K + j) * 2 + 1] = ok ? (int32_t)(a - base + row[j]) : (int32_t)g;
+            }
+        }
+    }
+    return 0;
+} catch (...) { return SRH_ERR_HIP; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // srh_pass2_votes + srh_edge_vote_accumulate in ONE pass, without materialising the votes (reference inferencer.py:206-228: the
 // (src, tgt)-keyed dicts).  The ~700k votes of a CityScale scene belong to only ~80k distinct edges, and every source point meets

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     const int lane = threadIdx.x & 63;
     const long pt = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pt >= (long)p.B * p.N) return;
-    const int b = pt / p.N;
+    const int b = p.point_tile ? p.point_tile[pt] : (int)(pt / p.N);
     const float px = point_coord(p.points, p.points_i64, pt * 2), py = point_coord(p.points, p.points_i64, pt * 2 + 1);
     // model.py:47 then ATen grid_sampler_unnormalize (align_corners=False)
     const float gx = (px / p.patch) * 2.0f - 1.0f, gy = (py / p.patch) * 2.0f - 1.0f;

@@ -236,6 +236,41 @@ def _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, lo=0):
     return out
 
 
+def _ragged_pass2(net, config):
+    """Pass 2 without padding (srh_toponet_ragged: one launch for all query rows of the scene's tiles) unless the config switches it
+    off (PASS2_RAGGED: False) or the model object has no such entry point (the CPU stand-in of the gloo tests)."""
+    v = config.PASS2_RAGGED
+    return (bool(v) if isinstance(v, bool) else True) and hasattr(net, "infer_toponet_ragged")
+
+
+def _pack_pass2_ragged(fq, K, alloc=None):
+    """Unpadded collate of ALL query rows of fq's tiles (srh_pass2_pack_ragged): (points f32 [R,2], point_tile i32 [R], pairs i32
+    [R,K,2], valid u8 [R,K]); rows keep their position in the flat query arrays, so tile t's scores are rows offsets[t] .. offsets[t+1]."""
+    if alloc is None:
+        alloc = lambda name, shape, dtype: np.zeros(shape, dtype)
+    from . import _lib
+    lib = _lib.load()
+    offsets = np.ascontiguousarray(fq.offsets, dtype=np.int64)
+    R = int(offsets[-1] - offsets[0])
+    pts_h = alloc("points", (max(R, 1), 2), np.float32)
+    tile_h = alloc("point_tile", (max(R, 1),), np.int32)
+    pairs_h = alloc("pairs", (max(R, 1), K, 2), np.int32)
+    valid_h = alloc("valid", (max(R, 1), K), np.uint8)
+    local = np.ascontiguousarray(fq.local, dtype=np.int64)
+    knn = np.ascontiguousarray(fq.knn, dtype=np.int32)
+    if lib.srh_pass2_pack_ragged(offsets.ctypes.data, local.ctypes.data, knn.ctypes.data, fq.n_tiles, K, pts_h.ctypes.data,
+                                 pairs_h.ctypes.data, valid_h.ctypes.data, tile_h.ctypes.data) != 0:
+        raise _lib.SrhError("srh_pass2_pack_ragged failed")
+    return R, pts_h, tile_h, pairs_h, valid_h
+
+
+def _ragged_batches(fq, scores_flat):
+    """The per-tile view _tile_slots / _vote_sums take, of one flat score array [R, K]: tile t = rows offsets[t] .. offsets[t+1]."""
+    off = np.asarray(fq.offsets, dtype=np.int64) - int(fq.offsets[0])
+    sc = np.ascontiguousarray(scores_flat, dtype=np.float32)
+    return [(np.array([t], dtype=np.int64), sc[off[t]:off[t + 1]][None]) for t in range(fq.n_tiles) if off[t + 1] > off[t]]
+
+
 def _tile_slots(fq, lo, batches, K):
     """Per-tile view of the score batches: [(tile, address of its f32 [n_max, K] block, n_max)] in ascending tile order, plus the
     arrays that keep the memory alive.  batches = [(tiles, scores [nb,n_max,K])] or, for consecutive tiles, [(off, end, scores)]
@@ -357,6 +392,20 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=False)
     # uploaded with one blocking copy each: per-batch non_blocking uploads of pageable numpy memory went through torch's
     # pinned-staging allocator and stalled 30-40 ms in some scenes (profiles/r02_scene_stages.txt).
     launched = []
+    if fq is not None and _ragged_pass2(net, config):
+        # every query row of this call's tiles in ONE unpadded launch (68 k padded rows -> 48 k real ones on a CityScale scene)
+        R, pts_h, tile_h, pairs_h, valid_h = _pack_pass2_ragged(fq, K)
+        if R == 0:
+            return empty
+        scores = net.infer_toponet_ragged(emb, *(torch.from_numpy(x[:R]).to(device) for x in (pts_h, tile_h, pairs_h, valid_h)))
+        scores = torch.where(torch.isnan(scores), -100.0, scores)
+        lap("collate + H2D + launch (ragged)")
+        host_scores = _ragged_batches(fq, scores.cpu().numpy())
+        if not raw:
+            out = _vote_sums(fq, lo, host_scores, n_pts, K)
+            lap("score fetch + vote sums")
+            return out
+        return _votes_from_scores(fq, lo, host_scores, n_pts, K)          # raw: the votes themselves, in visiting order
     if fq is not None:
         plan, pts_h, pairs_h, valid_h = _pack_pass2_batches(fq, lo, hi, bs, K)
         pts_d, pairs_d, valid_d = (torch.from_numpy(x).to(device) for x in (pts_h, pairs_h, valid_h))
@@ -697,6 +746,24 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None
         def alloc(name, shape, dtype):
             stage[name] = job.pool.get("up_" + name, shape, torch.from_numpy(np.zeros(0, dtype)).dtype)
             return stage[name].numpy()                 # srh_pass2_pack writes every row, padding included
+        if _ragged_pass2(net, config):                 # ONE unpadded launch for the scene's query rows (srh_toponet_ragged)
+            R = _pack_pass2_ragged(job.fq, K, alloc)[0]
+            job.plan = "ragged" if R else []
+            if not R:
+                return
+            pts_d, tile_d, pairs_d, valid_d = (lane.upload_staged(stage[n][:R]) for n in ("points", "point_tile", "pairs", "valid"))
+            if prof and lane.cuda:
+                job.t[2].record()
+            sc = net.infer_toponet_ragged(job.emb, pts_d, tile_d, pairs_d, valid_d)
+            sc = torch.where(torch.isnan(sc), -100.0, sc)
+            if prof and lane.cuda:
+                job.t[3].record()
+            job.scores, job.e2 = lane.download(job.pool, "score", [sc])
+            if prof and lane.cuda:
+                job.t[4].record()
+            job.emb = None
+            lap("pack + queue pass 2 (ragged)")
+            return
         job.plan = _pack_pass2_batches(job.fq, 0, job.n_tiles, bs, K, alloc)[0]
         if not job.plan:
             return
@@ -728,7 +795,9 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None
                 t = job.t
                 print(f"[infer_imgs] device: pass 1 {t[0].elapsed_time(t[1]):.1f} ms, mask download -> pass 2 start {t[1].elapsed_time(t[2]):.1f} ms, "
                       f"pass 2 {t[2].elapsed_time(t[3]):.1f} ms, score download {t[3].elapsed_time(t[4]):.1f} ms", flush=True)
-            job.votes = _vote_sums(job.fq, 0, [(tiles, sc.numpy()) for (tiles, _, _), sc in zip(job.plan, job.scores)], n_pts, K)
+            batches = _ragged_batches(job.fq, job.scores[0].numpy()) if job.plan == "ragged" else \
+                [(tiles, sc.numpy()) for (tiles, _, _), sc in zip(job.plan, job.scores)]
+            job.votes = _vote_sums(job.fq, 0, batches, n_pts, K)
         edges = votes_to_edges(*job.votes, n_pts, config.TOPO_THRESHOLD)
         lap("votes -> edges")
         return nodes, edges, job.kp_mask, job.road_mask

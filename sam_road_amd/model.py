@@ -450,6 +450,29 @@ class SAMRoad(nn.Module):
     def infer_toponet(self, image_embeddings, graph_points, pairs, valid):
         return self._topo(image_embeddings, graph_points, pairs, valid, False)[1]
 
+    @torch.no_grad()
+    def infer_toponet_ragged(self, image_embeddings, points, point_tile, pairs, valid):
+        """infer_toponet over the UNPADDED query rows of many tiles at once (pass 2 of infer_one_img, reference inferencer.py:179-207,
+        which pads every batch to its longest tile): image_embeddings [n,256,h,w] (the NCHW view of the library's channels-last
+        buffer), points f32 [R,2] tile-local (x, y), point_tile i32 [R] (index into image_embeddings), pairs i32 [R,K,2] (rows of
+        the flat list), valid u8 [R,K]  ->  scores f32 [R,K] (srh_toponet_ragged; rows as built by srh_pass2_pack_ragged)."""
+        dev = image_embeddings.device
+        ctx, wh = self._weights(dev)
+        emb = image_embeddings.permute(0, 2, 3, 1)
+        if emb.dtype != torch.float32 or not emb.is_contiguous():
+            emb = emb.to(torch.float32).contiguous()
+        R, K = int(pairs.shape[0]), int(pairs.shape[1])
+        pts = points.to(device=dev, dtype=torch.float32).contiguous()
+        pt = point_tile.to(device=dev, dtype=torch.int32).contiguous()
+        prs = pairs.to(device=dev, dtype=torch.int32).contiguous()
+        vld = valid.to(device=dev, dtype=torch.uint8).contiguous()
+        scores = torch.empty((R, K), dtype=torch.float32, device=dev)
+        if R * K > 0:
+            with torch.cuda.device(dev):
+                ctx.check(ctx.lib.srh_toponet_ragged(ctx.handle, wh, emb.data_ptr(), pts.data_ptr(), pt.data_ptr(), prs.data_ptr(),
+                                                     vld.data_ptr(), R, K, scores.data_ptr(), self._stream(dev)), "srh_toponet_ragged")
+        return scores
+
     # ---- scene level (pass 1 of infer_one_img: tile batcher + model + mask fusion) -------------------------
     @torch.no_grad()
     def scene_pass1(self, scene_u8, tile_xy, batch_size, canvas_kp=None, canvas_road=None):

@@ -126,7 +126,7 @@ def test_pass2_batching_sorted_vs_consecutive(pair):
     from sam_road_amd import Config
     from sam_road_amd import inferencer as inf
     _, net = pair
-    cfg = Config(CFG)
+    cfg = Config(dict(CFG, PASS2_RAGGED=False))         # the padded batches (the unpadded launch has no batches to group)
     imgs = [synth_scene(SCENE, seed=21), synth_scene(SCENE, seed=22)]
     assert inf.PASS2_SORT_TILES
     try:
@@ -140,6 +140,49 @@ def test_pass2_batching_sorted_vs_consecutive(pair):
     for a, b in zip(got[True], got[False]):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_pass2_ragged_rows_equal_padded_batches(pair):
+    """Pass 2 as ONE unpadded launch over all query rows of a scene (srh_toponet_ragged, the default) against the reference's padded
+    batches (PASS2_RAGGED: False; inferencer.py:179-207): every row is scored on its own, so nodes, masks and the edge list — order
+    included — are identical, through the serial call and through the pipelined loop; and at the op level the scores of the flat rows
+    are bit for bit the scores the padded call gives the same rows."""
+    from sam_road_amd import Config
+    from sam_road_amd import inferencer as inf
+    _, net = pair
+    imgs = [synth_scene(SCENE, seed=31), synth_scene(384, seed=32), synth_scene(SCENE, seed=33)]
+    got = {}
+    for ragged in (True, False):
+        cfg = Config(dict(CFG, PASS2_RAGGED=ragged))
+        got[ragged] = (list(inf.infer_imgs(net, iter(imgs), cfg, tile_sharded=False)), [inf.infer_one_img(net, im, cfg) for im in imgs])
+    assert got[True][0][0][0].shape[0] > 30 and got[True][0][0][1].shape[0] > 100
+    for runs in zip(got[True][0], got[False][0], got[True][1], got[False][1]):
+        for arrs in zip(*runs):
+            for other in arrs[1:]:
+                np.testing.assert_array_equal(np.asarray(arrs[0]), np.asarray(other))
+    # op level: a batch of tiles with different point counts, padded vs flat
+    cfg = Config(CFG)
+    dev = next(net.parameters()).device
+    img, infos, all_xy = inf._scene_plan(imgs[0], cfg)
+    scene = torch.as_tensor(np.ascontiguousarray(img)).to(dev)
+    _, _, emb = net.scene_pass1(scene, torch.as_tensor(all_xy).to(dev), int(cfg.INFER_BATCH_SIZE))
+    nodes = got[True][1][0][0][:, ::-1].copy()              # (x, y) graph points of the scene
+    fq = inf.build_all_patch_queries(np.ascontiguousarray(nodes), infos, 0, len(infos), cfg, flat=True)
+    K = int(cfg.MAX_NEIGHBOR_QUERIES)
+    R, p_h, t_h, q_h, v_h = inf._pack_pass2_ragged(fq, K)
+    flat = net.infer_toponet_ragged(emb, *(torch.from_numpy(x[:R]).to(dev) for x in (p_h, t_h, q_h, v_h))).cpu().numpy()
+    plan, pp, pq, pv = inf._pack_pass2_batches(fq, 0, len(infos), int(cfg.INFER_BATCH_SIZE), K)
+    pts_d, pairs_d, valid_d = (torch.from_numpy(x).to(dev) for x in (pp, pq, pv))
+    off = np.asarray(fq.offsets)
+    checked = 0
+    for tiles, sc in inf._launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K):
+        sc = sc.cpu().numpy()
+        for j, t in enumerate(tiles):
+            n = int(off[t + 1] - off[t])
+            vm = v_h[off[t]:off[t + 1]].astype(bool)
+            np.testing.assert_array_equal(sc[j, :n][vm], flat[off[t]:off[t + 1]][vm])
+            checked += int(vm.sum())
+    assert checked > 500
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the box (RCCL over xGMI); gpurun boxes expose one")

@@ -485,6 +485,49 @@ def test_pass2_pack_matches_per_tile_collate():
     assert sorted_rows <= scan_rows
 
 
+def test_pass2_ragged_pack_is_the_unpadded_collate():
+    """_pack_pass2_ragged (srh_pass2_pack_ragged: the rows of srh_toponet_ragged) == the per-tile (points, pairs, valid) tuples laid end
+    to end, pairs shifted to rows of the flat list, every row naming its tile; a tile's scores are rows offsets[t] .. offsets[t + 1]
+    (_ragged_batches feeds exactly those to the vote code), so the votes computed from a flat score array equal those computed from
+    the padded batches holding the same scores."""
+    from sam_road_amd import Config
+    from sam_road_amd import inferencer as inf
+    from sam_road_amd.tiling import get_patch_info_one_img
+    rng = np.random.default_rng(3)
+    cfg = Config(PATCH_SIZE=256, SAMPLE_MARGIN=16, INFER_PATCHES_PER_EDGE=4, NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16, INFER_BATCH_SIZE=5)
+    infos = get_patch_info_one_img(0, 640, 16, 256, 4)
+    pts = rng.integers(300, 640, size=(400, 2)).astype(np.int64)            # the top-left tiles stay empty
+    pts = pts[np.unique(pts[:, 0] * 1000 + pts[:, 1], return_index=True)[1]]
+    fq = inf.build_all_patch_queries(pts, infos, 0, len(infos), cfg, flat=True)
+    K = 16
+    junk = lambda name, shape, dtype: np.full(shape, 77, dtype)
+    R, p_h, t_h, q_h, v_h = inf._pack_pass2_ragged(fq, K, junk)
+    off = np.asarray(fq.offsets)
+    assert R == off[-1] and (np.diff(off) == 0).any()
+    for t in range(fq.n_tiles):
+        a, b = int(off[t]), int(off[t + 1])
+        _, tp, tq, tv = fq.tile(t)
+        np.testing.assert_array_equal(p_h[a:b], tp.astype(np.float32))
+        np.testing.assert_array_equal(q_h[a:b], tq.astype(np.int32) + a)            # tile-local indices -> rows of the flat list
+        np.testing.assert_array_equal(v_h[a:b], tv.astype(np.uint8))
+        assert (t_h[a:b] == t).all()
+    # votes from one flat score array == votes from padded batches holding the same scores
+    flat = rng.random((R, K)).astype(np.float32)
+    ragged = inf._ragged_batches(fq, flat)
+    plan, _ = inf._pass2_plan(fq, 5, sort_tiles=True)
+    padded = []
+    for tiles, n_max, _ in plan:
+        sc = np.zeros((len(tiles), n_max, K), np.float32)
+        for j, t in enumerate(tiles):
+            sc[j, :off[t + 1] - off[t]] = flat[off[t]:off[t + 1]]
+        padded.append((tiles, sc))
+    n_pts = pts.shape[0]
+    for x, y in zip(inf._vote_sums(fq, 0, ragged, n_pts, K), inf._vote_sums(fq, 0, padded, n_pts, K)):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    for x, y in zip(inf._votes_from_scores(fq, 0, ragged, n_pts, K), inf._votes_from_scores(fq, 0, padded, n_pts, K)):
+        assert np.array_equal(x, y)
+
+
 def test_pass2_vote_sums_equal_reference_dicts():
     """srh_pass2_vote_sums (rows grouped by source point, a table of targets per point) == the reference's dicts filled by the
     triple loop (inferencer.py:206-228): keys, float64 sums in visiting order, counts and insertion positions, bit for bit; any

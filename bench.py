@@ -15,7 +15,7 @@ rank runs its own batches — weak scaling, no data-path collective; weights are
 over RCCL before the timed region.  Prints ONE JSON line on rank 0.
 
 The line also carries
-  roofline      — the dominant kernel (the f16 MFMA GEMM, gemm_q192.hip / gemm.hip): algorithmic FLOPs of its launches
+  roofline      — the dominant kernel (the f16 MFMA GEMM, gemm_z192.hip / gemm.hip): algorithmic FLOPs of its launches
                   / their summed duration, measured with HIP events on the launch stream in an
                   instrumented pass of the same steps (events around every launch would perturb the
                   headline timing, so they are a separate pass over the same work);
@@ -481,7 +481,7 @@ def main():
         # the dominant kernel by GPU time: the four big linear layers of every block (one kernel template)
         block_gemm = [r for r in gemm if r["name"] in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")]
         d_fl, d_ms, d_n, d_ach = agg(block_gemm)
-        uses_q192 = WL["version"] == "vit_b" and B * (P // 16) ** 2 >= 8192
+        uses_z192 = WL["version"] == "vit_b" and B * (P // 16) ** 2 >= 8192
         # HBM bytes per GEMM launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command and workload
         # (tools/profile_gpu.sh + tools/summarize_profile.py -> profiles/<tag>_hbm_traffic[_<workload>].json).  A summary is used
         # ONLY if it was measured on this very build (it carries the library's build id); otherwise traffic is null
@@ -500,15 +500,15 @@ def main():
             break
         big = max(gemm, key=lambda r: r["ms"])["name"] if gemm else "none"
         kname = ("srh::gemm_z192_kernel (hand-scheduled persistent 256x192 f16 MFMA GEMM, one wave per SIMD, deferred epilogue: qkv / proj / fc1 / fc2) + small-layer GEMMs"
-                 if uses_q192 else
-                 "srh::gemm_glds_kernel / gemm_glds256_kernel (LDS-DMA 128x128 split-K and 256x256 f16 MFMA GEMMs: N, K not multiples of the q192 tile)")
+                 if uses_z192 else
+                 "srh::gemm_r8_kernel / gemm_r320_kernel / gemm_glds_kernel (LDS-DMA 128x256, 128x320 and 128x128 split-K f16 MFMA GEMMs: N, K not multiples of the z192 tile)")
         out["roofline"] = {"bound": "mfma", "kernel": kname, "largest_class": big,
                            "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
                            "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(fl / max(n, 1), 1),
                            "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
                            "dominant_kernel": {"what": "the block GEMMs alone (qkv, proj, fc1, fc2: one kernel template, " +
-                                                       ("gemm_z192_kernel" if uses_q192 else "gemm_glds*_kernel") + ")",
+                                                       ("gemm_z192_kernel" if uses_z192 else "gemm_glds*_kernel") + ")",
                                                "achieved": round(d_ach, 2), "frac": round(d_ach / MFMA_PEAK_TFLOPS, 4),
                                                "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 5),
                                                "algorithmic_flops_per_launch": round(d_fl / max(d_n, 1), 1)},

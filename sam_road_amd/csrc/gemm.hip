@@ -41,45 +41,65 @@ __device__ __forceinline__ const f16* a_src(const GemmParams& p, int m, int kt, 
 }
 
 // Epilogue shared by the GEMM kernels: lane holds, per (i,j,q), 4 consecutive columns n..n+3 of row m.
+// fp16 output without an f32 output: the register quads q = 2 k and 2 k + 1 of a row are exchanged between the two half-waves with one
+// v_permlane32_swap per packed register pair (half 0 ends up with columns 16 k .. 16 k + 7 of its row, half 1 with 16 k + 8 .. 16 k + 15),
+// so a lane stores 16 bytes instead of twice 8: a store instruction touches 32 rows either way and costs the CU's address path the same
+// ~87 ticks (profiles/r04_store_probe.txt) — half as many of them.
 template <int TN, int TM>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mw, int nw, int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
+    const bool f16_only = p.out_f16 && !p.out_f32;          // kernel-uniform
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mw + j * 32 + frow;
-        if (m >= p.M) continue;
+        const int mr = min(m, p.M - 1);                      // rows past M compute on a valid row (the exchange below needs every lane) and store nothing
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
+            float v[4][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = nw + i * 32 + 8 * q + 4 * fhalf;
-                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                for (int e = 0; e < 4; ++e) v[q][e] = acc[i][j][4 * q + e];
                 if (p.bias) {
                     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    v[q][0] += b.x; v[q][1] += b.y; v[q][2] += b.z; v[q][3] += b.w;
                 }
                 if (p.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                    for (int e = 0; e < 4; ++e) v[q][e] = gelu_fast(v[q][e]);
                 } else if (p.act == 2) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(v[q][e], 0.f);
                 }
                 if (p.pos) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.pos + (size_t)(m % p.pos_rows) * p.N + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    const float4 b = *reinterpret_cast<const float4*>(p.pos + (size_t)(mr % p.pos_rows) * p.N + n);
+                    v[q][0] += b.x; v[q][1] += b.y; v[q][2] += b.z; v[q][3] += b.w;
                 }
                 if (p.resid) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    const float4 b = *reinterpret_cast<const float4*>(p.resid + (size_t)mr * p.ldr + n);
+                    v[q][0] += b.x; v[q][1] += b.y; v[q][2] += b.z; v[q][3] += b.w;
                 }
-                if (p.out_f32)
-                    *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.out_f16) {
-                    f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                if (p.out_f32 && m < p.M)
+                    *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + n) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+                if (p.out_f16 && !f16_only && m < p.M) {
+                    f16x4 h = {(f16)v[q][0], (f16)v[q][1], (f16)v[q][2], (f16)v[q][3]};
                     *reinterpret_cast<f16x4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h;
+                }
+            }
+            if (f16_only) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f16x2 a0h = {(f16)v[2 * k][0], (f16)v[2 * k][1]}, a1h = {(f16)v[2 * k][2], (f16)v[2 * k][3]};
+                    const f16x2 b0h = {(f16)v[2 * k + 1][0], (f16)v[2 * k + 1][1]}, b1h = {(f16)v[2 * k + 1][2], (f16)v[2 * k + 1][3]};
+                    // swap(x, y): lanes 32..63 of x <-> lanes 0..31 of y; x = quad 2 k, y = quad 2 k + 1
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0h), __builtin_bit_cast(unsigned, b0h), false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1h), __builtin_bit_cast(unsigned, b1h), false, false);
+                    // half 0: (own quad 2 k | half 1's quad 2 k) = columns 16 k + 0..7; half 1: (half 0's quad 2 k + 1 | own quad 2 k + 1) = 16 k + 8..15
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ w = {r0[0], r1[0], r0[1], r1[1]};
+                    if (m < p.M)
+                        *reinterpret_cast<u32x4_*>(p.out_f16 + (size_t)m * p.ldc16 + nw + i * 32 + 16 * k + 8 * fhalf) = w;
                 }
             }
         }
@@ -594,6 +614,97 @@ void gemm_glds160_kernel(GemmParams p) {
     epilogue<5, 1>(p, acc, m0 + wave * 32, n0, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gemm_r320_kernel (round 5): 128(M) x 320(N) x 64 tiles, EIGHT waves (4 along M x 2 along N, the 32 x 160 wave tile of
+// gemm_glds160_kernel), two 56-KiB stages, one workgroup per CU, LDS-DMA from inline asm (see gemm_r8_kernel).  For the small-M layers
+// that are one round of such tiles — ViT-H fc1 at M = 2048: 16 x 16 = 256 tiles.  Why the wider tile: these layers are bound by the
+// rate at which operand bytes reach LDS, and a 128 x 320 tile moves M N K 2 (1/128 + 1/320) bytes against (1/128 + 1/160) for
+// 128 x 160 — 293 instead of 377 MB for fc1 (profiles/r05_vith_gemm_r8.txt).  Why two stages suffice here and not in gemm_glds_kernel:
+// there the compiler puts a vmcnt(0) in front of the fragment reads (it cannot tell the stages of one dynamic LDS block apart), so the
+// DMA of k-tile kt + 1 had to LAND before k-tile kt was computed and only a second resident workgroup covered it; with the DMA issued
+// from inline asm the compiler knows of nothing to wait for, and the DMA of k-tile kt + 1 lands under the MFMAs of k-tile kt.
+// tests/test_isa_contract.py checks the loop on the emitted ISA: 7 LDS-DMA per k-tile and wave, no other VMEM operation.
+// ---------------------------------------------------------------------------------------------------
+constexpr int R320_BM = 128, R320_BN = 320, R320_XT = R320_BM * BK * 2, R320_WT = R320_BN * BK * 2, R320_STAGE = R320_XT + R320_WT;
+constexpr int R320_LDS = 2 * R320_STAGE;           // 114 688 B
+
+__global__ __launch_bounds__(512, 1) void gemm_r320_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + R320_BM - 1) / R320_BM, p.N / R320_BN, tile_m, tile_n);
+    const int m0 = tile_m * R320_BM, n0 = tile_n * R320_BN;
+    const int nk = p.K / BK;
+
+    // DMA pieces of a k-tile (8 rows x 128 B, swizzle on the source side): X has 16 (wave w: w, w + 8), W has 40 (w, w + 8, .., w + 32)
+    const int prow = lane >> 3, pc = lane & 7;
+    unsigned xoff[2], woff[5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 8 + wave) * 8 + prow;
+        xoff[i] = (unsigned)((min(m0 + r, p.M - 1) * p.lda + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = (i * 8 + wave) * 8 + prow;
+        woff[i] = (unsigned)(((n0 + r) * p.ldw + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+    const char* const abase = reinterpret_cast<const char*>(p.A);
+    const char* const wbase = reinterpret_cast<const char*>(p.W);
+    auto dma_ktile = [&](int kt, int stage) {
+        const char* a = abase + (size_t)kt * (BK * 2);
+        const char* w = wbase + (size_t)kt * (BK * 2);
+        const unsigned d = lds0 + stage * R320_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16_saddr(xoff[i], a, d + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma16_saddr(woff[i], w, d + R320_XT + i * 8192);
+    };
+
+    f32x16 acc[5][1];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int x_row0 = (wm * 32) * 128, w_row0 = (wn * 160) * 128;
+
+    dma_ktile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // k-tile kt has landed (this wave's pieces: nothing else is in flight)
+        __syncthreads();                                     // ... every wave's; and every wave is done with the other stage (k-tile kt - 1)
+        dma_ktile(min(kt + 1, nk - 1), stage ^ 1);           // the tail re-fetches the last k-tile (no branch around the asm)
+        const char* sa = smem + stage * R320_STAGE + x_row0;
+        const char* sw = smem + stage * R320_STAGE + R320_XT + w_row0;
+        f16x8 fwA[5], fwB[5], fxA, fxB;
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG160(fwA, fxA, 0)
+        SRH_FRAG160(fwB, fxB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA160(fwA, fxA)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG160(fwA, fxA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA160(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_FRAG160(fwB, fxB, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        SRH_MMA160(fwA, fxA)
+        SRH_MMA160(fwB, fxB)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail's redundant fetch must not outlive the workgroup's LDS
+    epilogue<5, 1>(p, acc, m0 + wm * 32, n0 + wn * 160, lane);
+}
+
 // out = act(sum_z partial[z] + bias) (+ resid): the partial sums are added in ascending z (fixed order: deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     const size_t quad = (size_t)blockIdx.x * 256 + threadIdx.x;          // 4 consecutive columns
@@ -837,6 +948,17 @@ static bool use_tile160(const GemmParams& p) {
 // 240 tiles, 28.7 -> 26.5 us; ViT-L qkv / fc1).  With split-K for the few-tile layers (ViT-H proj / fc2: 80 tiles x 3 slices) it measured
 // WORSE than the 128 x 128 kernels (proj 26.8 vs 18.9 us, fc2 45.6 vs 46.3, profiles/r05_vith_gemm_r8.txt): the kernel keeps the split-K
 // code path (probe variant 45) but the dispatch does not use it.
+static bool r320_applies(const GemmParams& p) {     // ViT-H fc1-like: one round of 128 x 320 tiles where 128 x 256 tiles would need two
+#ifdef SRH_TUNING      // probe builds: A/B switch
+    static const bool on = !(getenv("SRH_GEMM_R320") && atoi(getenv("SRH_GEMM_R320")) == 0);
+    if (!on) return false;
+#endif
+    if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % R320_BN != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p)) return false;
+    const long t320 = (long)((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN);
+    const long t256 = p.N % R8_BN == 0 ? (long)((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN) : 1 << 30;
+    return t320 >= 160 && t320 <= 256 && t256 > 256;
+}
+
 static bool r8_applies(const GemmParams& p) {
 #ifdef SRH_TUNING      // probe builds: A/B switch
     static const bool on = !(getenv("SRH_GEMM_R8") && atoi(getenv("SRH_GEMM_R8")) == 0);
@@ -849,7 +971,7 @@ static bool r8_applies(const GemmParams& p) {
 
 // Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
 int gemm_splitk_factor(const GemmParams& p) {
-    if (r8_applies(p)) return 1;
+    if (r8_applies(p) || r320_applies(p)) return 1;
     if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
     if (p.M >= 4096 || z192_preferred(p)) return 1;
     if (use_tile160(p)) return 1;
@@ -898,6 +1020,11 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
             *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
             return true;
         }
+        case 46:                                   // the 128 x 320 kernel
+            if (p.N % R320_BN != 0) return true;
+            hipLaunchKernelGGL(gemm_r320_kernel, dim3(((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN), 1), dim3(512), R320_LDS, stream, p);
+            *rc = launched();
+            return true;
         case 45:                                   // the 8-wave ring kernel with the caller's split-K
             if (p.N % R8_BN != 0) return true;
             hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), sk), dim3(512), R8_LDS, stream, p);
@@ -941,7 +1068,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (!opt_in.run([] {
             const std::pair<const void*, int> k[] = {
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds160_kernel), 73728},
-                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072}, {reinterpret_cast<const void*>(gemm_r8_kernel), R8_LDS},
+                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072}, {reinterpret_cast<const void*>(gemm_r8_kernel), R8_LDS}, {reinterpret_cast<const void*>(gemm_r320_kernel), R320_LDS},
 #ifdef SRH_TUNING
                 {reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), 65536},
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), 65536}, {reinterpret_cast<const void*>(gemm_glds256_kernel<1>), 131072},
@@ -961,6 +1088,12 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
     if (p.N % 256 == 0 && p.M >= 4096 && p.K > 256 && fits256) {
         hipLaunchKernelGGL(gemm_glds256_kernel<0>, dim3((unsigned)t256), dim3(512), 131072, stream, p);
+        return launched();
+    }
+    if (r320_applies(p)) {                        // ... or in one round of 128 x 320 tiles (ViT-H fc1)
+        GemmParams q = p;
+        q.splitk = 1;
+        hipLaunchKernelGGL(gemm_r320_kernel, dim3(((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN), 1), dim3(512), R320_LDS, stream, q);
         return launched();
     }
     if (r8_applies(p)) {                          // small-M layers in one round of 128 x 256 tiles on the 8-wave ring kernel

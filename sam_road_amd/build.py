@@ -15,6 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # The softmax row maxima are taken over MFMA results; without this flag every fmaxf operand gets a v_max x, x to quiet a
 # possible signalling NaN first (16 extra VALU instructions per 64 keys in a VALU-bound loop).  No NaN arises in these kernels
 # (-inf - finite and exp2(-inf) are fine); infinities ARE used, so no -ffinite-math-only.
+# PRECONDITION this puts on the callers: q / k / v must be finite.  A NaN already in qkv16 (an fp16 overflow upstream) would no longer
+# propagate deterministically through fmaxf / the online softmax; every whole-model test asserts finite outputs (tests/test_gpu_*.py:
+# torch.isfinite on embeddings and masks, incl. the heavy-tailed-weights cases that push fp16 hardest), which is where such an input would show.
 FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "attention_hdx.hip": ["-fno-honor-nans"]}
 
 

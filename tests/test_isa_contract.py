@@ -128,3 +128,20 @@ def test_attention_output_stores_are_16_bytes():
     body = _kernel_body(_isa("attention.hip", ["-fno-honor-nans"]), "attn_window_kernel")
     assert len(re.findall(r"global_store_dwordx4", body)) >= 4 and not re.findall(r"global_store_dwordx2", body)
     assert len(re.findall(r"v_permlane32_swap", body)) >= 8
+
+
+def test_gemm_r320_loop_is_seven_dma_pieces_and_nothing_else():
+    """gemm_r320_kernel (two stages, inline-asm LDS-DMA, inline-asm vmcnt(0) + barrier per k-tile): the wait is exact only if nothing but
+    the 7 pieces of the next k-tile is issued between two waits — no compiler-inserted VMEM operation (a spill), no compiler-inserted wait."""
+    body = _kernel_body(_isa("gemm.hip"), "gemm_r320_kernel")
+    assert "scratch_" not in body
+    ev = _vmem_events(body)
+    i = ev.index(0)                                          # the loop's wait
+    assert ev[:i] == ["D"] * 7, ev[:i]                       # prologue: k-tile 0
+    assert ev[i + 1] == "B"
+    j = i + 2
+    trip = []
+    while j < len(ev) and ev[j] != 0:
+        trip.append(ev[j])
+        j += 1
+    assert trip == ["D"] * 7, trip

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0, '$R'); from sam_road_amd import _lib; print(_lib.build_id())" > $R/gpurun_out/${TAG}_build_id.txt
 cd /tmp
-BENCH="python $R/bench.py --workload $WORKLOAD --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-reference-gpu --no-sustained --no-scene"
+BENCH="python $R/bench.py --workload $WORKLOAD --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-reference-gpu --no-sustained --no-scene --no-workloads"
 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- $BENCH > $R/gpurun_out/${TAG}_prof.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pmc_fetch -o pmc -- $BENCH > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_pmc_write -o pmc -- $BENCH > $R/gpurun_out/${TAG}_pmc_write.log 2>&1

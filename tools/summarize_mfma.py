@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "*counter_collection.csv")):
         if not name.startswith("srh::"):
             continue
         acc[(name, r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE, bench.py --steps 6 (per-launch means), round 4 build")
+print("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE, bench.py --steps 6 (per-launch means)")
 print("# MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)")
 for (name, grid), c in sorted(acc.items()):
     m = lambda k: sum(c[k]) / max(len(c[k]), 1)

@@ -501,7 +501,7 @@ def main():
         big = max(gemm, key=lambda r: r["ms"])["name"] if gemm else "none"
         kname = ("srh::gemm_z192_kernel (hand-scheduled persistent 256x192 f16 MFMA GEMM, one wave per SIMD, deferred epilogue: qkv / proj / fc1 / fc2) + small-layer GEMMs"
                  if uses_z192 else
-                 "srh::gemm_r8_kernel / gemm_r320_kernel / gemm_glds_kernel (LDS-DMA 128x256, 128x320 and 128x128 split-K f16 MFMA GEMMs: N, K not multiples of the z192 tile)")
+                 "srh::gemm_pp_kernel / gemm_r320_kernel / gemm_ring_kernel (LDS-DMA f16 MFMA GEMMs: 128x256 ping-pong incl. split-K slices folded by the next LayerNorm, 128x320, 128x128 ring; small M, where the z192 tile does not fill the chip)")
         out["roofline"] = {"bound": "mfma", "kernel": kname, "largest_class": big,
                            "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",

@@ -739,7 +739,11 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
     // LayerNorm — it only normalises x + delta16 — and the next block's first LayerNorm folds both branches, (x + delta16) +
     // delta16b, and writes x once per block: 275 instead of 300 MB of LayerNorm traffic per block at B = 16, same sums in the
     // same order bit for bit.
+    // Small-M models (ViT-H / ViT-L at 256 px): fc2 runs with split-K, and instead of a reduce pass its f32 partials stay in the
+    // workspace for the next LayerNorm pass (or the neck's cast) to fold — x += (slice 0 + slice 1 + ...) + bias, the reduce kernel's
+    // order, same bits — one launch and one round trip of x less per block.
     bool pend_a = false, pend_b = false;                  // delta16 (proj) / delta16b (fc2) hold a branch output not yet added to x
+    int pend_slices = 0; const float* pend_bias = nullptr; // split-K partials of the last branch GEMM wait in c->split_ws
     auto branch_gemm = [&](const char* cls, const f16* A, int lda, const f16* W, int K, const float* bias, bool second, int a_blocked = 0) -> int {
         GemmParams gq;
         gq.A = A; gq.lda = lda; gq.W = W; gq.ldw = K; gq.M = T; gq.N = D; gq.K = K; gq.bias = bias; gq.a_blocked16 = a_blocked;
@@ -747,7 +751,19 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         if (z192_preferred(gq)) { (second ? pend_b : pend_a) = true; return gemm(c, cls, gq, s); }
         GemmParams gp = gq;
         gp.out_f16 = nullptr; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
+        if (const int sk = gemm_splitk_factor(gp); sk > 1 && bias && (D == 1024 || D == 1280) && !pend_slices) {
+            gp.defer_reduce = 1;
+            pend_slices = sk; pend_bias = bias;
+        }
         return gemm(c, cls, gp, s);
+    };
+    auto fold_pending = [&](NormParams& ln, int& reads) {  // what the pass has to add to x before normalising / casting
+        if (pend_slices) {
+            ln.slices = c->split_ws.as<float>(); ln.nslices = pend_slices; ln.slice_stride = (size_t)T * D; ln.slice_bias = pend_bias;
+            reads = 2 * pend_slices;                      // in units of 2 bytes per element, as the fp16 branches
+        } else if (pend_a && pend_b) { ln.delta16 = c->delta16.as<f16>(); ln.delta16b = c->delta16b.as<f16>(); reads = 2; }
+        else if (pend_a) { ln.delta16 = c->delta16.as<f16>(); reads = 1; }
+        else if (pend_b) { ln.delta16 = c->delta16b.as<f16>(); reads = 1; }
     };
     bool defer_x = false;                                 // both branch GEMMs of the blocks take z192 (same shapes in every block)
     {
@@ -764,13 +780,11 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         ln.x = c->x.as<float>(); ln.M = T; ln.D = D; ln.eps = 1e-6f; ln.out_f16 = c->xn16.as<f16>();
         ln.gamma = gamma; ln.beta = beta;
         int reads = 0;
-        if (pend_a && pend_b) { ln.delta16 = c->delta16.as<f16>(); ln.delta16b = c->delta16b.as<f16>(); reads = 2; }
-        else if (pend_a) { ln.delta16 = c->delta16.as<f16>(); reads = 1; }
-        else if (pend_b) { ln.delta16 = c->delta16b.as<f16>(); reads = 1; }
-        const bool wr = write_x && reads > 0;
+        fold_pending(ln, reads);
+        const bool wr = (write_x || pend_slices) && reads > 0;   // partials cannot wait: the next split-K GEMM overwrites the workspace
         ln.x_out = wr ? c->x.as<float>() : nullptr;
         TRYK(c, "layernorm", 0, (double)T * D * (4 + 2 + 2 * reads + (wr ? 4 : 0)), s, launch_layernorm(ln, s));
-        if (wr) pend_a = pend_b = false;
+        if (wr) { pend_a = pend_b = false; pend_slices = 0; }
         return 0;
     };
     for (const BlockW& b : w->blocks) {
@@ -809,9 +823,7 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         NormParams cast;
         cast.x = c->x.as<float>(); cast.M = T; cast.D = D; cast.out_f16 = c->xn16.as<f16>();
         int reads = 0;                                               // the last block's branch outputs, if still pending
-        if (pend_a && pend_b) { cast.delta16 = c->delta16.as<f16>(); cast.delta16b = c->delta16b.as<f16>(); reads = 2; }
-        else if (pend_a) { cast.delta16 = c->delta16.as<f16>(); reads = 1; }
-        else if (pend_b) { cast.delta16 = c->delta16b.as<f16>(); reads = 1; }
+        fold_pending(cast, reads);
         TRYK(c, "layernorm", 0, (double)T * D * (6 + 2 * reads), s, launch_layernorm(cast, s));
         GemmParams g;
         g.A = c->xn16.as<f16>(); g.lda = D; g.W = w->neck0_w; g.ldw = D; g.M = T; g.N = 256; g.K = D;

@@ -410,17 +410,16 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// gemm_r8_kernel (round 5) — the small-M layers of ViT-H / ViT-L at 256 px again (M = 2048 rows): 128(M) x 256(N) x 64 tiles, EIGHT waves
-// (2 x 4 wave tiles of 64 x 64: two waves per SIMD), a three-stage ring of 48 KiB stages (one workgroup per CU), LDS-DMA two k-tiles
-// ahead.  Against gemm_ring_kernel: twice the MFMA work per k-tile and per barrier on the same DMA latency, and ViT-H's qkv (480 tiles of
-// 128 x 128 = two workgroups on every CU with one k-tile of lookahead each) becomes 240 tiles = one round.  What it is bound by: the rate at
-// which a CU's address path takes LDS-DMA pieces (a 128 x 256 k-tile is 48 KiB for 1024 clk of MFMA per SIMD; the path sustains ~34 B/clk:
-// ~1450 clk), measured 1.1 us per k-tile on 240 CUs against 0.72 on 80 — small-M tiles move too many operand bytes per FLOP through it.
+// gemm_r8_kernel (round 5; a PROBE kernel since gemm_pp_kernel below took its layers) — 128(M) x 256(N) x 64 tiles, EIGHT waves (2 x 4 wave
+// tiles of 64 x 64: two waves per SIMD), a three-stage ring of 48 KiB stages (one workgroup per CU), LDS-DMA two k-tiles ahead, ONE barrier
+// per k-tile.  Its ablations (probe variants 47-49, 39; profiles/r05_vith_gemm_pp.txt) are what led to the ping-pong loop: 1.04 us per
+// k-tile, of which the DMA stream alone needs 0.57, fragment reads + MFMA alone 0.76 and the MFMAs 0.5-0.66 — the parts add up instead of
+// overlapping, because the barrier keeps the two waves of every SIMD in lockstep.
 // The LDS-DMA is issued from INLINE ASM and waited for with an inline-asm counted s_waitcnt (the form found for the persistent attention
 // experiment, attention.hip): the compiler does not know that LDS-DMA is in flight, so the ring needs neither one static LDS object per
 // stage nor an unrolled stage sequence — the stage is a runtime offset into one dynamic LDS block — and no conservative vmcnt(0) appears
-// before LDS reads.  What that leaves to this code (checked by tests/test_isa_contract.py on the emitted ISA: exactly 6 LDS-DMA and no
-// other VMEM operation per k-tile and wave): RAW — k-tile kt is read behind "s_waitcnt vmcnt(6); s_barrier" (6 = the pieces of k-tile
+// before LDS reads.  What that leaves to this code (exactly 6 LDS-DMA and no other VMEM operation per k-tile and wave; tests/test_isa_contract.py
+// checks that on the emitted ISA of gemm_pp_kernel and gemm_r320_kernel): RAW — k-tile kt is read behind "s_waitcnt vmcnt(6); s_barrier" (6 = the pieces of k-tile
 // kt + 1, the only younger operations); WAR — the DMA of k-tile kt + 2 goes into the stage of k-tile kt - 1 and is issued behind that
 // barrier, which every wave passes only after its last fragment read of k-tile kt - 1 has been consumed by an MFMA.
 // ---------------------------------------------------------------------------------------------------
@@ -428,9 +427,10 @@ __device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, un
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_wave_uniform) : "memory");
 }
 
+
+#ifdef SRH_TUNING      // a probe kernel since gemm_pp_kernel took its layers (variants 45, 47-49, 39)
 constexpr int R8_BM = 128, R8_BN = 256, R8_XT = R8_BM * BK * 2, R8_WT = R8_BN * BK * 2, R8_STAGE = R8_XT + R8_WT, R8_NST = 3;
 constexpr int R8_LDS = R8_NST * R8_STAGE;          // 147 456 B
-
 __global__ __launch_bounds__(512, 1) void gemm_r8_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
@@ -491,27 +491,41 @@ __global__ __launch_bounds__(512, 1) void gemm_r8_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // k-tile kt has landed (this wave's pieces); k-tile kt + 1 may stay in flight
         __syncthreads();                                     // ... every wave's pieces; and every wave is done with k-tile kt - 1's stage
         const int nxt = stage == 0 ? R8_NST - 1 : stage - 1; // (stage + NST - 1) % NST: the stage k-tile kt - 1 used
-        dma_ktile(min(kt + R8_NST - 1, klast), nxt);         // the tail re-fetches the last k-tile: the counts above stay exact
-        // (issuing the six pieces two at a time behind the first three MFMA groups instead measured the same: the k-tile is bound by the
-        // rate at which the CU's address path accepts LDS-DMA pieces, not by where the wave issues them — profiles/r05_vith_gemm_r8.txt)
+#ifdef SRH_TUNING      // probe builds (gemm_probe variants 47 / 48 / 49 via prio_mode): what is the k-tile made of?
+        if (p.prio_mode == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // 2: no DMA inside the loop (stale operands)
+        else
+#endif
+        dma_ktile(
+#ifdef SRH_TUNING
+            p.prio_mode == 4 ? kt0 :             // 4: DMA + barriers only, and every k-tile re-fetches k-tile 0 (an L2-resident footprint)
+#endif
+            min(kt + R8_NST - 1, klast), nxt);         // the tail re-fetches the last k-tile: the counts above stay exact
+        // (issuing the six pieces two at a time behind the first three MFMA groups instead measured the same, profiles/r05_vith_gemm_r8.txt)
         const char* sa = smem + stage * R8_STAGE + x_row0;
         const char* sw = smem + stage * R8_STAGE + R8_XT + w_row0;
         f16x8 fwA[2], fxA[2], fwB[2], fxB[2];
+#ifdef SRH_TUNING
+        if (p.prio_mode >= 3) { stage = stage == R8_NST - 1 ? 0 : stage + 1; continue; }   // 3: DMA + barriers only
+#define R8_MMA(fw, fx) { if (p.prio_mode != 1) SRH_MMA2(fw, fx) else { asm volatile("" :: "v"(fw[0]), "v"(fw[1]), "v"(fx[0]), "v"(fx[1])); } }   /* 1: fragment reads, no MFMA */
+#else
+#define R8_MMA(fw, fx) SRH_MMA2(fw, fx)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         SRH_FRAG2(fwA, fxA, 0)
         SRH_FRAG2(fwB, fxB, 1)
         __builtin_amdgcn_sched_barrier(0);
-        SRH_MMA2(fwA, fxA)
+        R8_MMA(fwA, fxA)
         __builtin_amdgcn_sched_barrier(0);
         SRH_FRAG2(fwA, fxA, 2)
         __builtin_amdgcn_sched_barrier(0);
-        SRH_MMA2(fwB, fxB)
+        R8_MMA(fwB, fxB)
         __builtin_amdgcn_sched_barrier(0);
         SRH_FRAG2(fwB, fxB, 3)
         __builtin_amdgcn_sched_barrier(0);
-        SRH_MMA2(fwA, fxA)
-        SRH_MMA2(fwB, fxB)
+        R8_MMA(fwA, fxA)
+        R8_MMA(fwB, fxB)
         __builtin_amdgcn_sched_barrier(0);
+#undef R8_MMA
         stage = stage == R8_NST - 1 ? 0 : stage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail's redundant fetches have landed
@@ -524,6 +538,153 @@ __global__ __launch_bounds__(512, 1) void gemm_r8_kernel(GemmParams p) {
         return;
     }
     epilogue_staged<2, 0>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_pp_kernel (round 5) — gemm_r8_kernel's tile, ring and DMA with a PING-PONG k-loop: the two waves of a SIMD (waves w and w + 4)
+// are half a k-tile apart.  Every k-tile has a MEMORY slot (issue this wave's six pieces of k-tile kt + 2, read ALL sixteen fragments of
+// k-tile kt into registers) and a COMPUTE slot (sixteen MFMAs out of registers, raised priority), one s_barrier between slots; group 0
+// (waves 0-3) is in its memory slot while group 1 (waves 4-7) computes and the other way round, so the matrix pipe of every SIMD always
+// has one wave with nothing but MFMAs to issue and the LDS / address paths always serve the other one.  Why: r8's ablations
+// (profiles/r05_vith_gemm_r8.txt) — per 128 x 256 x 64 k-tile 0.51 us of MFMA, 0.57 us for the DMA + barriers alone, 0.76 us for fragment
+// reads + MFMA without DMA, 1.04 us all together: with one barrier per k-tile the two waves of a SIMD run in lockstep (both read, both
+// multiply), and nothing overlaps.
+//   slot:     2k                2k+1              2k+2
+//   group 0:  MEM(k)            CMP(k)            MEM(k+1)
+//   group 1:  CMP(k-1)          MEM(k)            CMP(k)
+// RAW: k-tile k is read from slot 2k on; every wave waits for its own pieces of k-tile k (vmcnt(6): only k-tile k + 1's are younger)
+// before the barrier that opens slot 2k — group 0 at the end of CMP(k-1), group 1 at the end of MEM(k-1).  WAR: MEM(k) sends k-tile
+// k + 2 into the stage of k-tile k - 1, last read in slot 2k-1 (group 1's MEM(k-1), lgkmcnt(0) before its barrier).  Compute slots never
+// touch LDS.  Both groups pass the same number of barriers (group 1 one before the loop, group 0 one after its last compute slot).
+// ---------------------------------------------------------------------------------------------------
+// Two geometries (PpCfg): 128 x 256 with 2 x 4 wave tiles of 64 x 64 (qkv-like layers, and fc2-like ones with split-K), and 256 x 160
+// with eight stacked 32 x 160 wave tiles (fc1-like layers whose 128 x 256 tiling would spill into a second round: ViT-H fc1 at M = 2048
+// is exactly 256 such tiles).  The second has 52 pieces per k-tile for 8 waves: group 0's waves send 7, group 1's send 6 — the counted
+// waits are per group anyway.
+template <int CFG> struct PpCfg;
+template <> struct PpCfg<0> { static constexpr int BM = 128, BN = 256, WAVES_M = 2, TXF = 2, TWF = 2; };
+template <> struct PpCfg<1> { static constexpr int BM = 256, BN = 160, WAVES_M = 8, TXF = 1, TWF = 5; };
+template <int CFG> constexpr int pp_lds_bytes() { return 3 * (PpCfg<CFG>::BM + PpCfg<CFG>::BN) * BK * 2; }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int CFG>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
+    using C = PpCfg<CFG>;
+    constexpr int BM = C::BM, BN = C::BN, TXF = C::TXF, TWF = C::TWF, XT = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int XP = BM / 64, WP = BN / 64, WX = (BN / 8) % 8;       // pieces per wave: X, W (every wave), and WX waves send one more W piece
+    static_assert(WX == 0 || WX == 4, "the odd W pieces go to exactly group 0's four waves");
+    constexpr int NP0 = XP + WP + (WX ? 1 : 0), NP1 = XP + WP;          // pieces per k-tile of a group-0 / group-1 wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                       // waves w and w + 4 share a SIMD: they are the ping and the pong
+    const int wm = C::WAVES_M == 8 ? wave : wave >> 2, wn = C::WAVES_M == 8 ? 0 : wave & 3;
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + BM - 1) / BM, p.N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nsplit = p.splitk > 1 ? p.splitk : 1, zsplit = blockIdx.y;
+    const int kt0 = zsplit * (p.K / BK) / nsplit, nk = (zsplit + 1) * (p.K / BK) / nsplit;
+
+    // DMA pieces of a k-tile: 8 rows x 128 B each (1 KiB), swizzle on the source side; wave w sends pieces w, w + 8, ...
+    const int prow = lane >> 3, pc = lane & 7;
+    unsigned xoff[XP], woff[WP + 1];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int r = (i * 8 + wave) * 8 + prow;
+        xoff[i] = (unsigned)((min(m0 + r, p.M - 1) * p.lda + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WP + 1; ++i) {
+        const int r = min((i * 8 + wave) * 8 + prow, BN - 1);
+        woff[i] = (unsigned)(((n0 + r) * p.ldw + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+    const char* const abase = reinterpret_cast<const char*>(p.A);
+    const char* const wbase = reinterpret_cast<const char*>(p.W);
+    const int klast = nk - 1;
+    auto dma_ktile = [&](int kt, int stage) {
+        const char* a = abase + (size_t)kt * (BK * 2);
+        const char* w = wbase + (size_t)kt * (BK * 2);
+        const unsigned d = lds0 + stage * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) dma16_saddr(xoff[i], a, d + i * 8192);
+#pragma unroll
+        for (int i = 0; i < WP; ++i) dma16_saddr(woff[i], w, d + XT + i * 8192);
+        if (WX && !grp) dma16_saddr(woff[WP], w, d + XT + WP * 8192);
+    };
+    auto wait_next = [&](bool last) {                       // this wave's pieces of the NEXT k-tile have landed (only the one after may be in flight)
+        if (last) wait_vmcnt<0>();
+        else if (grp) wait_vmcnt<NP1>();
+        else wait_vmcnt<NP0>();
+    };
+
+    f32x16 acc[TWF][TXF];
+#pragma unroll
+    for (int i = 0; i < TWF; ++i)
+#pragma unroll
+        for (int j = 0; j < TXF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fkey = (frow >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
+    const int w_row0 = (wn * TWF * 32) * 128, x_row0 = (wm * TXF * 32) * 128;
+
+    dma_ktile(min(kt0, klast), 0);
+    dma_ktile(min(kt0 + 1, klast), 1);
+    wait_next(false);
+    __syncthreads();                                         // k-tile kt0 has landed, everyone's pieces
+    if (grp) __syncthreads();                                // group 1 sits out slot 0
+    int stage = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+        // ---- memory slot: all fragments of k-tile kt into registers, then this wave's pieces of k-tile kt + 2 into the stage of kt - 1
+        const int nxt = stage == 0 ? 2 : stage - 1;
+        const char* sa = smem + stage * STAGE + x_row0;
+        const char* sw = smem + stage * STAGE + XT + w_row0;
+        f16x8 fw[4][TWF], fx[4][TXF];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TWF; ++i) fw[ks][i] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + i * 4096);
+#pragma unroll
+            for (int j = 0; j < TXF; ++j) fx[ks][j] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + j * 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_ktile(min(kt + 2, klast), nxt);                  // the tail re-fetches the last k-tile: the counts stay exact
+        if (grp) wait_next(kt == klast);                     // group 1: k-tile kt + 1 before the barrier that opens slot 2 (kt + 1)
+        __syncthreads();                                     // (lgkmcnt(0): the fragments are in registers, the stage may be overwritten)
+        // ---- compute slot
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < TWF; ++i)
+#pragma unroll
+                for (int j = 0; j < TXF; ++j) acc[i][j] = mfma32(fw[ks][i], fx[ks][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!grp) {
+            wait_next(kt == klast);
+            __syncthreads();
+        } else if (kt != klast) {
+            __syncthreads();
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    // every piece has landed and every fragment read has completed before the last barrier anyone passed: the ring is staging space
+    GemmParams q = p;
+    if (nsplit > 1) {  // raw f32 partial sums; bias / residual / activation are applied by splitk_reduce_kernel
+        q.bias = nullptr; q.resid = nullptr; q.pos = nullptr; q.act = 0; q.out_f16 = nullptr;
+        q.out_f32 = p.split_ws + (size_t)zsplit * p.M * p.N; q.ldc = p.N;
+    }
+    if constexpr (CFG == 0) epilogue_staged<2, 0>(q, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+    else epilogue<TWF, TXF>(q, acc, m0 + wm * TXF * 32, n0 + wn * TWF * 32, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -944,10 +1105,6 @@ static bool use_tile160(const GemmParams& p) {
     return t128 > 512 && t160 <= 512;
 }
 
-// gemm_r8_kernel's share of the small-M layers: those that are ONE round of 128 x 256 tiles with at least ~5/8 of the CUs busy (ViT-H qkv:
-// 240 tiles, 28.7 -> 26.5 us; ViT-L qkv / fc1).  With split-K for the few-tile layers (ViT-H proj / fc2: 80 tiles x 3 slices) it measured
-// WORSE than the 128 x 128 kernels (proj 26.8 vs 18.9 us, fc2 45.6 vs 46.3, profiles/r05_vith_gemm_r8.txt): the kernel keeps the split-K
-// code path (probe variant 45) but the dispatch does not use it.
 static bool r320_applies(const GemmParams& p) {     // ViT-H fc1-like: one round of 128 x 320 tiles where 128 x 256 tiles would need two
 #ifdef SRH_TUNING      // probe builds: A/B switch
     static const bool on = !(getenv("SRH_GEMM_R320") && atoi(getenv("SRH_GEMM_R320")) == 0);
@@ -955,26 +1112,46 @@ static bool r320_applies(const GemmParams& p) {     // ViT-H fc1-like: one round
 #endif
     if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % R320_BN != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p)) return false;
     const long t320 = (long)((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN);
-    const long t256 = p.N % R8_BN == 0 ? (long)((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN) : 1 << 30;
+    const long t256 = p.N % 256 == 0 ? (long)((p.M + 127) / 128) * (p.N / 256) : 1 << 30;
     return t320 >= 160 && t320 <= 256 && t256 > 256;
 }
 
-static bool r8_applies(const GemmParams& p) {
+// gemm_pp_kernel<0>'s share of the small-M layers (profiles/r05_vith_gemm_pp.txt):
+//   * those that are ONE round of 128 x 256 tiles with at least ~5/8 of the CUs busy — ViT-H qkv: 240 tiles, 30.4 (gemm_r8_kernel, round 5's
+//     first answer, now a probe kernel) -> 25.5 us; ViT-L qkv / fc1;
+//   * the few-tile deep-K ones with split-K — ViT-H fc2: 80 tiles x 3 slices, 43.6 us with the reduce pass against 45.9 on 128 x 128 tiles.
+// ViT-H proj (80 tiles, K = 1280: slices of 6 k-tiles) stays on the 128 x 128 ring kernel (18.4 against 22.9 / 25.7 us).
+static bool pp_shape_ok(const GemmParams& p) {
 #ifdef SRH_TUNING      // probe builds: A/B switch
-    static const bool on = !(getenv("SRH_GEMM_R8") && atoi(getenv("SRH_GEMM_R8")) == 0);
+    static const bool on = !(getenv("SRH_GEMM_PP") && atoi(getenv("SRH_GEMM_PP")) == 0);
     if (!on) return false;
 #endif
-    if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % R8_BN != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p)) return false;
-    const long tiles = (long)((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN);
+    return !(p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % 256 != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p));
+}
+static bool pp_applies(const GemmParams& p) {
+    if (!pp_shape_ok(p)) return false;
+    const long tiles = (long)((p.M + 127) / 128) * (p.N / 256);
     return tiles >= 160 && tiles <= 256;
 }
+static int pp_split_factor(const GemmParams& p) {           // > 1: gemm_pp_kernel<0> with that many K slices
+    if (!pp_shape_ok(p) || p.M % 128 != 0) return 1;
+    const long tiles = (long)(p.M / 128) * (p.N / 256);
+    const int nk = p.K / BK;
+    if (tiles > 128 || nk < 48) return 1;
+    int s = (int)(256 / tiles);
+    if (s > 4) s = 4;
+    while (s > 1 && nk / s < 24) --s;
+    if (tiles * s < 192) return 1;             // too few workgroups for one per CU (ViT-L fc2: 64 tiles x 2: 37.1 against 36.1 us)
+    return s;
+}
 
-// Split-K only pays when the 128x128 tiles cannot fill the chip's 512 workgroup slots and K is deep enough to share out.
+// Split-K only pays when the tiles cannot fill the chip's workgroup slots and K is deep enough to share out.
 int gemm_splitk_factor(const GemmParams& p) {
-    if (r8_applies(p) || r320_applies(p)) return 1;
+    if (pp_applies(p) || r320_applies(p)) return 1;
     if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M % 128 != 0 || p.N % 128 != 0 || p.K % BK != 0) return 1;
     if (p.M >= 4096 || z192_preferred(p)) return 1;
     if (use_tile160(p)) return 1;
+    if (const int s = pp_split_factor(p); s > 1) return s;
     const long tiles = (long)(p.M / 128) * (p.N / 128);
     const int nk = p.K / BK;
     if (tiles >= 224 || nk < 16) return 1;
@@ -1025,6 +1202,28 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
             hipLaunchKernelGGL(gemm_r320_kernel, dim3(((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN), 1), dim3(512), R320_LDS, stream, p);
             *rc = launched();
             return true;
+        case 39: case 47: case 48: case 49: {      // r8 ablations: 47 no MFMA, 48 no DMA in the loop, 49 DMA + barriers only, 39 = 49 on one k-tile
+            if (p.N % R8_BN != 0) return true;
+            GemmParams q = p;
+            q.prio_mode = variant == 39 ? 4 : variant - 46; q.splitk = 1;
+            hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), 1), dim3(512), R8_LDS, stream, q);
+            *rc = launched();
+            return true;
+        }
+        case 33: case 35: {                        // the ping-pong kernel, 128 x 256: 35 no split-K, 33 the caller's
+            if (p.N % 256 != 0) return true;
+            GemmParams q = p; q.splitk = variant == 33 ? sk : 1;
+            hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(((p.M + 127) / 128) * (p.N / 256), q.splitk), dim3(512), pp_lds_bytes<0>(), stream, q);
+            *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
+            return true;
+        }
+        case 34: {                                 // the ping-pong kernel, 256 x 160
+            if (p.N % 160 != 0) return true;
+            GemmParams q = p; q.splitk = 1;
+            hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(((p.M + 255) / 256) * (p.N / 160), 1), dim3(512), pp_lds_bytes<1>(), stream, q);
+            *rc = launched();
+            return true;
+        }
         case 45:                                   // the 8-wave ring kernel with the caller's split-K
             if (p.N % R8_BN != 0) return true;
             hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), sk), dim3(512), R8_LDS, stream, p);
@@ -1068,8 +1267,13 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (!opt_in.run([] {
             const std::pair<const void*, int> k[] = {
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds160_kernel), 73728},
-                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072}, {reinterpret_cast<const void*>(gemm_r8_kernel), R8_LDS}, {reinterpret_cast<const void*>(gemm_r320_kernel), R320_LDS},
+                {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072},
 #ifdef SRH_TUNING
+                {reinterpret_cast<const void*>(gemm_r8_kernel), R8_LDS},
+#endif
+                {reinterpret_cast<const void*>(gemm_pp_kernel<0>), pp_lds_bytes<0>()}, {reinterpret_cast<const void*>(gemm_r320_kernel), R320_LDS},
+#ifdef SRH_TUNING
+                {reinterpret_cast<const void*>(gemm_pp_kernel<1>), pp_lds_bytes<1>()},
                 {reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), 65536},
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), 65536}, {reinterpret_cast<const void*>(gemm_glds256_kernel<1>), 131072},
                 {reinterpret_cast<const void*>(gemm_glds256_kernel<2>), 131072},
@@ -1096,10 +1300,10 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(gemm_r320_kernel, dim3(((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN), 1), dim3(512), R320_LDS, stream, q);
         return launched();
     }
-    if (r8_applies(p)) {                          // small-M layers in one round of 128 x 256 tiles on the 8-wave ring kernel
+    if (pp_applies(p)) {                          // small-M layers in one round of 128 x 256 tiles on the ping-pong kernel
         GemmParams q = p;
         q.splitk = 1;
-        hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), 1), dim3(512), R8_LDS, stream, q);
+        hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(((p.M + 127) / 128) * (p.N / 256), 1), dim3(512), pp_lds_bytes<0>(), stream, q);
         return launched();
     }
     const int grid = ((p.M + 127) / 128) * (p.N / 128);
@@ -1111,8 +1315,11 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     }
     if (p.split_ws && p.splitk > 1) {             // deterministic split-K: f32 partials + a reduce pass in ascending slice order
         if (p.splitk != gemm_splitk_factor(p) || p.splitk > (p.K / BK)) return -2;
-        hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid, p.splitk), dim3(256), 65536, stream, p);
-        return launch_splitk_reduce(p, stream);
+        if (p.splitk == pp_split_factor(p))       // few 128 x 256 tiles, deep K: the ping-pong kernel's slices
+            hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3((p.M / 128) * (p.N / 256), p.splitk), dim3(512), pp_lds_bytes<0>(), stream, p);
+        else
+            hipLaunchKernelGGL((gemm_glds_kernel<0, 2>), dim3(grid, p.splitk), dim3(256), 65536, stream, p);
+        return p.defer_reduce ? launched() : launch_splitk_reduce(p, stream);
     }
     // at most one 128 x 128 tile per CU and a k-loop long enough to fill a ring: the three-stage ring kernel (one workgroup per CU, the
     // L2 / HBM latency hidden by depth instead of by a second resident workgroup): ViT-H proj 21.3 -> 18.3 us (profiles/r04_gemm_ring_vith.txt)

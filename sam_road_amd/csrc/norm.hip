@@ -11,7 +11,7 @@ namespace srh {
 // R rows per wave per iteration (all R rows' loads are issued before any is consumed: the kernel is
 // latency-bound otherwise — PMC showed >90 % of wave cycles parked in s_waitcnt with one row in flight),
 // grid-stride over row groups.
-template <int EPL, int VW, int R, int NT = 0>  // elements per lane, vector width (floats), rows per wave per iteration, nontemporal x loads (2) / x_out stores (1)
+template <int EPL, int VW, int R, int NT = 0, bool SL = false>  // elements per lane, vector width (floats), rows per wave per iteration, nontemporal x loads (2) / x_out stores (1), split-K slices folded
 __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     const int lane = threadIdx.x & 63;
     constexpr int NV = EPL / VW;
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
         float v[R][EPL];
         f16 dl[R][EPL];                                   // optional fp16 residual-branch output to fold in (dead when unused)
         f16 dl2[R][EPL];                                  // optional second one (delta16b)
+        float sl[SL ? R : 1][SL ? EPL : 1];               // optional split-K partials of the preceding GEMM, summed in slice order
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = min(row0 + r, p.M - 1);
@@ -70,6 +71,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
                     }
                 }
             }
+            if constexpr (SL && VW == 4) {
+                {
+                    const float* sp = p.slices + (size_t)row * p.D;
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        const float4 t = *reinterpret_cast<const float4*>(sp + (c * 64 + lane) * 4);
+                        sl[r][c * 4] = t.x; sl[r][c * 4 + 1] = t.y; sl[r][c * 4 + 2] = t.z; sl[r][c * 4 + 3] = t.w;
+                    }
+                    for (int z = 1; z < p.nslices; ++z) {
+                        sp += p.slice_stride;
+#pragma unroll
+                        for (int c = 0; c < NV; ++c) {
+                            const float4 t = *reinterpret_cast<const float4*>(sp + (c * 64 + lane) * 4);
+                            sl[r][c * 4] += t.x; sl[r][c * 4 + 1] += t.y; sl[r][c * 4 + 2] += t.z; sl[r][c * 4 + 3] += t.w;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.slice_bias + (c * 64 + lane) * 4);
+                        sl[r][c * 4] += t.x; sl[r][c * 4 + 1] += t.y; sl[r][c * 4 + 2] += t.z; sl[r][c * 4 + 3] += t.w;
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
                 const int off = (c * 64 + lane) * VW;
@@ -87,9 +111,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
-            if (p.delta16) {                              // x <- x + delta (the residual add the GEMM epilogue no longer does)
+            if (SL || p.delta16) {                        // x <- x + delta (the residual add the GEMM epilogue no longer does)
+                if constexpr (SL) {                       // (sum of the K slices + bias) + x: splitk_reduce_kernel's order
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) v[r][e] += (float)dl[r][e];
+                    for (int e = 0; e < EPL; ++e) v[r][e] = sl[r][e] + v[r][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) v[r][e] += (float)dl[r][e];
+                }
                 if (p.delta16b) {                         // (x + first) + second: the order in which the reference adds its two branches
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) v[r][e] += (float)dl2[r][e];
@@ -144,15 +173,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
     }
 }
 
-template <int EPL, int VW, int R, int NT = 0>
+template <int EPL, int VW, int R, int NT = 0, bool SL = false>
 static void launch_ln(const NormParams& p, hipStream_t s) {
     const int groups = (p.M + R - 1) / R;                 // wave-iterations needed
     const int blocks = min((groups + 3) / 4, 256 * 8);    // <= 8 blocks per CU, grid-stride beyond
-    hipLaunchKernelGGL((layernorm_kernel<EPL, VW, R, NT>), dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((layernorm_kernel<EPL, VW, R, NT, SL>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 int launch_layernorm(const NormParams& p, hipStream_t s) {
     if (p.M <= 0) return 0;
+    if (p.slices) {      // the small-M models' pass after a split-K fc2 (api.hip): its own instantiations, the others stay as they were
+        if (p.delta16 || p.delta16b || p.nslices < 1 || !p.slice_bias) return -2;
+        switch (p.D) {
+            case 1024: launch_ln<16, 4, 2, 0, true>(p, s); break;
+            case 1280: launch_ln<20, 4, 2, 0, true>(p, s); break;
+            default: return -2;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     switch (p.D) {
         case 128:  launch_ln<2, 2, 4>(p, s); break;
         case 256:  launch_ln<4, 4, 4>(p, s); break;

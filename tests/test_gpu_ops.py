@@ -29,8 +29,11 @@ def _sync():
 
 @pytest.mark.parametrize("M,N,K,act,resid", [(256, 128, 64, 0, False), (300, 256, 192, 1, False),
                                               (1000, 768, 768, 0, True), (128, 384, 3072, 2, False),
-                                              # small-M layers of ViT-H at 256 px: the deterministic split-K path (3 / 4 K-slices)
+                                              # small-M layers of ViT-H at 256 px: the deterministic split-K paths — 3 slices of 128 x 256
+                                              # tiles on the ping-pong kernel (fc2), the ring kernel without split (proj), 4 slices of 128 x 128
                                               (2048, 1280, 5120, 0, True), (2048, 1280, 1280, 1, False), (256, 768, 3072, 0, True),
+                                              # one round of 128 x 256 tiles on the ping-pong kernel: ragged M, the shortest k-loops (6 / 7 k-tiles)
+                                              (2000, 3840, 384, 1, False), (2048, 3840, 448, 0, True), (1536, 4096, 1024, 2, True),
                                               # ViT-H fc1 at M = 2048: 640 tiles of 128x128 -> the 128x160 kernel (512 tiles, one round);
                                               # with a ragged M (1990 rows: the last tile row is partly empty) and with a residual
                                               (2048, 5120, 320, 1, False), (1990, 5120, 192, 0, True)])
@@ -74,7 +77,7 @@ def test_gemm(ctx, M, N, K, act, resid):
     (12288, 1536, 768, 0, True),      # z192: 384 tiles on 256 workgroups: some walk two tiles, some one
     (16384, 768, 3072, 2, False),     # ReLU, no bias: no generated body -> the 256 x 256 LDS-DMA kernel (gemm_glds256_kernel)
     (8192, 1536, 768, 0, False),      # no bias -> the 256 x 256 kernel
-    (2048, 3840, 1280, 0, True),      # ViT-H qkv at 256 px: 480 tiles of 128 x 128, two workgroups per CU, no split-K (gemm_glds_kernel)
+    (2048, 3840, 1280, 0, True),      # ViT-H qkv at 256 px: 240 tiles of 128 x 256, one round of the ping-pong kernel (gemm_pp_kernel)
 ])
 def test_gemm_big_fp16_layers(ctx, M, N, K, act, use_bias):
     """fp16-output layers: the persistent 256 x 192 kernel (csrc/gemm_z192.hip, generated body) where it applies — bias, act none /

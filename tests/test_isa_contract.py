@@ -102,26 +102,6 @@ def _vmem_events(body):
     return ev
 
 
-def test_gemm_r8_ring_counts_are_what_the_source_assumes():
-    """gemm_r8_kernel issues its LDS-DMA from inline asm and waits with an inline-asm vmcnt(6): the compiler knows nothing about either,
-    so the count is only right if a wave's k-loop contains exactly 6 LDS-DMA operations per trip and NO other VMEM operation (a spill, a
-    hoisted load) — checked on the ISA hipcc emits.  Prologue: two k-tiles = 12 pieces before the loop."""
-    isa = _isa("gemm.hip")
-    body = _kernel_body(isa, "gemm_r8_kernel")
-    assert "scratch_" not in body, "gemm_r8_kernel spills: the vmcnt(6) of its ring is no longer exact"
-    ev = _vmem_events(body)
-    i = ev.index(6)                                          # the loop's counted wait
-    assert ev[:i].count("D") == 12 and "L" not in ev[:i] and "S" not in ev[:i], ev[:i]
-    assert ev[i + 1] == "B", ev[i:i + 3]
-    j = i + 2
-    trip = []
-    while j < len(ev) and ev[j] != 0:                        # up to the tail's vmcnt(0)
-        trip.append(ev[j])
-        j += 1
-    assert trip == ["D"] * 6, f"one k-tile of the ring must be exactly 6 LDS-DMA operations, got {trip}"
-    assert ev[j] == 0 and ev[j + 1] == "B", ev[j:j + 3]
-
-
 def test_attention_output_stores_are_16_bytes():
     """store_query: one v_permlane32_swap per pair of register quads, then 4 stores of 16 bytes per lane (was 8 of 8 bytes) — the store
     path's cost is per instruction (32 token rows each either way)."""
@@ -145,3 +125,43 @@ def test_gemm_r320_loop_is_seven_dma_pieces_and_nothing_else():
         trip.append(ev[j])
         j += 1
     assert trip == ["D"] * 7, trip
+
+
+def test_gemm_pp_slots_hold_exactly_what_the_counted_waits_assume():
+    """gemm_pp_kernel<0> (ping-pong k-loop, inline-asm LDS-DMA and counted waits): per k-tile a wave reads 16 fragments, sends exactly 6
+    pieces, computes 16 MFMAs between two barriers — and the only vmcnt waits are the group's own (6: the next k-tile landed, the one
+    after may fly; 0 on the last k-tile).  Anything else the compiler added (a spill, a hoisted load, a conservative wait) breaks the
+    count or the overlap."""
+    body = _kernel_body(_isa("gemm.hip"), "gemm_pp_kernelILi0E")
+    assert "scratch_" not in body
+    ev = []
+    for ln in body.split("\n"):
+        t = ln.split(";")[0].strip()
+        if t.startswith("s_barrier"):
+            ev.append("B")
+        elif re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t):
+            ev.append(int(re.search(r"vmcnt\((\d+)\)", t).group(1)))
+        elif "global_load_lds" in t:
+            ev.append("D")
+        elif re.match(r"(global|buffer|flat|scratch)_(load|store)", t):
+            ev.append("V")
+        elif t.startswith("ds_read"):
+            ev.append("R")
+        elif t.startswith("v_mfma"):
+            ev.append("M")
+    first_m = ev.index("M")
+    last_m = len(ev) - 1 - ev[::-1].index("M")
+    pro, loop = ev[:first_m], ev[first_m:last_m + 1]
+    assert pro.count("D") == 18 and "V" not in pro, pro       # two k-tiles before the loop + the first memory slot's six
+    assert pro.count("R") == 16, pro
+    assert loop.count("M") == 16 and "V" not in loop and "D" not in loop and "R" not in loop, loop     # the compute slot is MFMAs only
+    # the memory slot (between the loop's closing barrier and the barrier before the MFMAs): reads first, then six pieces, then the wait
+    k = len(pro) - 1 - pro[::-1].index("B")                   # the barrier that opens the compute slot
+    j = k - 1
+    while pro[j] != "B":
+        j -= 1
+    slot = pro[j + 1:k]
+    assert [e for e in slot if e in ("R", "D")] == ["R"] * 16 + ["D"] * 6, slot
+    assert [e for e in slot if isinstance(e, int)] in ([6, 0], [0, 6]), slot          # group 1's two alternatives, nothing else
+    tail = ev[last_m + 1:]                                    # group 1's closing barrier, then group 0's wait (6, or 0 on the last k-tile) and barrier
+    assert tail[:4] in (["B", 6, 0, "B"], ["B", 0, 6, "B"], [6, 0, "B", "B"], [0, 6, "B", "B"]), tail[:8]

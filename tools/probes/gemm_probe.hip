@@ -75,7 +75,12 @@ int main(int argc, char** argv) {
                          {"hproj", T, D, D, 0, false, true}, {"hfc2", T, D, 4 * D, 0, false, true},
                          // ViT-H at 256 px, B = 8 (BASELINE configs[4]): M = 2048 tokens, D = 1280 — the small-M regime of gemm_glds_kernel
                          {"vh_qkv", 2048, 3840, 1280, 0, false, true}, {"vh_proj", 2048, 1280, 1280, 0, true, false},
-                         {"vh_fc1", 2048, 5120, 1280, 1, false, true}, {"vh_fc2", 2048, 1280, 5120, 0, true, false}};
+                         {"vh_fc1", 2048, 5120, 1280, 1, false, true}, {"vh_fc2", 2048, 1280, 5120, 0, true, false},
+                         // the K slope of a one-round launch (240 tiles of 128 x 256): time per k-tile without launch / epilogue
+                         // ViT-L at 256 px, B = 8: D = 1024
+                         {"vl_qkv", 2048, 3072, 1024, 0, false, true}, {"vl_proj", 2048, 1024, 1024, 0, true, false},
+                         {"vl_fc1", 2048, 4096, 1024, 1, false, true}, {"vl_fc2", 2048, 1024, 4096, 0, true, false},
+                         {"kx1", 2048, 3840, 1280, 0, false, true}, {"kx2", 2048, 3840, 2560, 0, false, true}, {"kx4", 2048, 3840, 5120, 0, false, true}};
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     for (const Shape& s : all) {
@@ -113,6 +118,7 @@ int main(int argc, char** argv) {
             // variant 0 = what the library would do: split-K where its heuristic asks for it; 31 = 128x160 tiles with split-K 4
             if (variant == 0) { GemmParams t = g; t.variant = 0; const int sk = gemm_splitk_factor(t); if (sk > 1) { g.splitk = sk; g.split_ws = ws; } }
             if (variant == 31) { g.splitk = 4; g.split_ws = ws; }
+            if (variant == 33) { g.splitk = getenv("PROBE_SPLITK") ? atoi(getenv("PROBE_SPLITK")) : 3; g.split_ws = ws; }
             if (variant == 97) { g.variant = 70; g.out_blocked16 = 1; }
             if (variant > 70 && variant <= 70 + z192_var_count() && z192_var_out_blocked(variant - 70) && s.act == 1) g.out_blocked16 = 1;
             if (variant == 98) { g.variant = 70; g.a_blocked16 = 1; g.A = dA_blk; }

@@ -26,6 +26,9 @@ $HIPCC $FLAGS -c tools/probes/attention_g64.hip -o tools/probes/build/attention_
 $HIPCC $FLAGS -c tools/probes/attn_win_probe.hip -o tools/probes/build/attn_win_probe.o &
 wait
 $HIPCC --offload-arch=gfx950 tools/probes/build/attn_win_probe.o tools/probes/build/attention.o tools/probes/build/attention_g64.o tools/probes/build/attention_hdx.o -o tools/probes/attn_win_probe
+# head-dim-80 attention (ViT-H) alone, with its ablations
+$HIPCC $FLAGS -c tools/probes/hdx_probe.hip -o tools/probes/build/hdx_probe.o
+$HIPCC --offload-arch=gfx950 tools/probes/build/hdx_probe.o tools/probes/build/attention_hdx.o -o tools/probes/hdx_probe
 for p in feed_probe pipe_probe mfma_probe dma_probe feedx_probe mfma_data_probe store_probe trans_probe ln_probe; do
   [ -f tools/probes/$p.hip ] && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p
 done

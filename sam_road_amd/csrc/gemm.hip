@@ -687,6 +687,152 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     else epilogue<TWF, TXF>(q, acc, m0 + wm * TXF * 32, n0 + wn * TWF * 32, lane);
 }
 
+#ifdef SRH_TUNING
+// ---------------------------------------------------------------------------------------------------
+// gemm_ppk_kernel (round 5; PROBE builds only, variant 32: measured, correct, not faster) — the ping-pong loop for 128(M) x 320(N) tiles
+// (ViT-H fc1 at M = 2048: exactly 256 tiles) with the two groups splitting K instead of the tile.  The idea: if the ping-pong kernels
+// were bound by LDS bandwidth (fragment reads + LDS-DMA writes: 176 KiB per 128 x 256 k-tile; the 256 x 160 geometry with 32 x 160 wave
+// tiles needs 244 KiB and is slower), a LARGE wave tile — 64 x 160, ten accumulator tiles, 0.7 KiB of fragments per MFMA — would lift
+// it; eight such waves would be a 256 x 320 tile, so the two waves of a SIMD work on the SAME 64 x 160 output tile and
+// alternate over K: the k dimension is walked in half k-tiles of 32; group 0 (waves 0-3, 2 x 2 wave tiles) multiplies the even ones,
+// group 1 the odd ones, each into its own accumulators; slots as in gemm_pp_kernel (a group reads the 14 fragments of its half k-tile
+// and sends seven 1-KiB pieces — 16 rows x 64 B — of its half k-tile four ahead while the other group issues 20 MFMAs).  A half
+// k-tile is 28 KiB; five ring stages (140 KiB) hold the one being read and the four in flight; a stage is written only by its own
+// group.  At the end the groups exchange partial sums through the ring and each finishes half of the 64 x 160 tile:
+// out = (even-k sum) + (odd-k sum) — a fixed order, not the ascending-k order of the other kernels.
+// RAW: a wave waits for its own pieces of its group's next half k-tile (vmcnt(7): only the seven just sent are younger) before the
+// barrier that precedes that memory slot; WAR: the stage of half k-tile h + 4 is the stage of h - 1, read by the OTHER group one slot
+// earlier, behind a barrier.
+// Result (profiles/r05_vith_gemm_pp.txt): 1.03-1.09 us per 128 x 320 k-tile = 4.8-5.1 TFLOP/s per CU in the loop — the SAME per-CU
+// rate as gemm_pp_kernel and gemm_z192 with a third less LDS traffic per FLOP (so LDS bandwidth is not what they share), and 39.7 us on
+// ViT-H fc1 against 37.1 for gemm_r320_kernel: the partial-sum exchange and the larger epilogue cost more than the loop gains.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PPK_BM = 128, PPK_BN = 320, PPK_XT = PPK_BM * 64, PPK_STAGE = (PPK_BM + PPK_BN) * 64, PPK_NST = 5;
+constexpr int PPK_LDS = PPK_NST * PPK_STAGE;       // 143 360 B
+
+__global__ __launch_bounds__(512, 1) void gemm_ppk_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;        // waves w and w + 4 share a SIMD and an output tile; the group is the parity of the half k-tile
+    const int wm = w4 & 1, wn = w4 >> 1;             // 2 (M) x 2 (N) wave tiles of 64 x 160
+    int tile_m, tile_n;
+    tile_of_block<8>((p.M + PPK_BM - 1) / PPK_BM, p.N / PPK_BN, tile_m, tile_n);
+    const int m0 = tile_m * PPK_BM, n0 = tile_n * PPK_BN;
+    const int nk = p.K / BK;                         // iterations: one half k-tile per group each
+    const int hlast = 2 * (nk - 1) + grp;            // this group's last half k-tile
+
+    // pieces of a half k-tile: 16 rows x 64 B (four lanes per row), swizzle on the source side; X has 8, W has 20; the owning group's
+    // wave w4 sends X pieces w4, w4 + 4 and W pieces w4, w4 + 4, ..., w4 + 16
+    const int prow = lane >> 2, pc = lane & 3;
+    unsigned xoff[2], woff[5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 4 + w4) * 16 + prow;
+        xoff[i] = (unsigned)((min(m0 + r, p.M - 1) * p.lda + ((pc ^ ((r >> 2) & 3)) * 8)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = (i * 4 + w4) * 16 + prow;
+        woff[i] = (unsigned)(((n0 + r) * p.ldw + ((pc ^ ((r >> 2) & 3)) * 8)) * 2);
+    }
+    const char* const abase = reinterpret_cast<const char*>(p.A);
+    const char* const wbase = reinterpret_cast<const char*>(p.W);
+    auto dma_half = [&](int h, int stage) {
+        const char* a = abase + (size_t)h * 64;
+        const char* w = wbase + (size_t)h * 64;
+        const unsigned d = lds0 + stage * PPK_STAGE + w4 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16_saddr(xoff[i], a, d + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma16_saddr(woff[i], w, d + PPK_XT + i * 4096);
+    };
+
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 64 + (((ks * 2 + fhalf) ^ ((frow >> 2) & 3)) << 4);
+    const int x_row0 = (wm * 64) * 64, w_row0 = (wn * 160) * 64;
+
+    int stage = grp;                                  // stage of half k-tile h is h % 5
+    dma_half(min(grp, hlast), stage);
+    dma_half(min(grp + 2, hlast), stage + 2);
+    wait_vmcnt<7>();
+    __syncthreads();                                  // this group's first half k-tile has landed
+    if (grp) __syncthreads();                         // group 1 sits out slot 0
+    for (int i = 0; i < nk; ++i) {
+        const int h = 2 * i + grp;
+        // ---- memory slot
+        const char* sa = smem + stage * PPK_STAGE + x_row0;
+        const char* sw = smem + stage * PPK_STAGE + PPK_XT + w_row0;
+        f16x8 fw[2][5], fx[2][2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) fw[ks][t] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + t * 2048);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fx[ks][t] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + t * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_half(min(h + 4, hlast), stage == 0 ? 4 : stage - 1);      // (h + 4) % 5 = (h - 1) % 5; the tail re-fetches: the counts stay exact
+        __syncthreads();                              // (lgkmcnt(0): the fragments are in registers)
+        // ---- compute slot
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[t][j] = mfma32(fw[ks][t], fx[ks][j], acc[t][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == nk - 1) wait_vmcnt<0>();
+        else wait_vmcnt<7>();                         // this group's next half k-tile (sent two iterations ago) has landed
+        if (!grp || i != nk - 1) __syncthreads();
+        stage = stage >= 3 ? stage - 3 : stage + 2;
+    }
+    // ---- the two groups' partial sums: through the ring (nothing is in flight, nobody reads fragments any more).  Group 0 finishes N
+    // tiles 0, 1 and the upper half of tile 4, group 1 tiles 2, 3 and the lower half of tile 4: 80 registers travel each way, as 16-byte
+    // chunks (conflict-free: lane-consecutive), 20 KiB per wave pair and direction, one direction at a time.
+    __syncthreads();
+    char* const xch = smem + w4 * (20 * 1024) + lane * 16;
+    auto put = [&](int g, const f32x16& a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xch + (g * 4 + q) * 1024) = f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+    };
+    auto add = [&](int g, f32x16& a) {                 // a = received + a
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xch + (g * 4 + q) * 1024);
+            a[4 * q] = t[0] + a[4 * q]; a[4 * q + 1] = t[1] + a[4 * q + 1]; a[4 * q + 2] = t[2] + a[4 * q + 2]; a[4 * q + 3] = t[3] + a[4 * q + 3];
+        }
+    };
+    if (grp) { put(0, acc[0][0]); put(1, acc[0][1]); put(2, acc[1][0]); put(3, acc[1][1]); put(4, acc[4][0]); }
+    __syncthreads();
+    if (!grp) { add(0, acc[0][0]); add(1, acc[0][1]); add(2, acc[1][0]); add(3, acc[1][1]); add(4, acc[4][0]); }
+    __syncthreads();
+    if (!grp) { put(0, acc[2][0]); put(1, acc[2][1]); put(2, acc[3][0]); put(3, acc[3][1]); put(4, acc[4][1]); }
+    __syncthreads();
+    if (grp) { add(0, acc[2][0]); add(1, acc[2][1]); add(2, acc[3][0]); add(3, acc[3][1]); add(4, acc[4][1]); }
+    __syncthreads();                                   // the exchange area becomes the staged epilogue's per-wave transposition buffers
+    f32x16 fin[2][2], last[1][1];                      // (no runtime index into acc: that would move the accumulators to scratch)
+    if (grp) { fin[0][0] = acc[2][0]; fin[0][1] = acc[2][1]; fin[1][0] = acc[3][0]; fin[1][1] = acc[3][1]; last[0][0] = acc[4][1]; }
+    else { fin[0][0] = acc[0][0]; fin[0][1] = acc[0][1]; fin[1][0] = acc[1][0]; fin[1][1] = acc[1][1]; last[0][0] = acc[4][0]; }
+    epilogue_staged<2, 0>(p, fin, smem + wave * 16384, m0 + wm * 64, n0 + wn * 160 + grp * 64, lane);
+    epilogue<1, 1>(p, last, m0 + wm * 64 + grp * 32, n0 + wn * 160 + 128, lane);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // 128(M) x 160(N) x 64 LDS-DMA variant for the SMALL-M layers whose 128x128 tile count misses the chip's 512 workgroup slots
 // (two workgroups per CU): ViT-H at 256 px, B = 8 has M = 2048 rows, and fc1 (N = 5120) is 640 tiles of 128x128 = two rounds
@@ -1217,6 +1363,11 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
             *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
             return true;
         }
+        case 32:                                   // the K-parity ping-pong kernel, 128 x 320
+            if (p.N % PPK_BN != 0) return true;
+            hipLaunchKernelGGL(gemm_ppk_kernel, dim3(((p.M + PPK_BM - 1) / PPK_BM) * (p.N / PPK_BN), 1), dim3(512), PPK_LDS, stream, p);
+            *rc = launched();
+            return true;
         case 34: {                                 // the ping-pong kernel, 256 x 160
             if (p.N % 160 != 0) return true;
             GemmParams q = p; q.splitk = 1;
@@ -1273,7 +1424,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
 #endif
                 {reinterpret_cast<const void*>(gemm_pp_kernel<0>), pp_lds_bytes<0>()}, {reinterpret_cast<const void*>(gemm_r320_kernel), R320_LDS},
 #ifdef SRH_TUNING
-                {reinterpret_cast<const void*>(gemm_pp_kernel<1>), pp_lds_bytes<1>()},
+                {reinterpret_cast<const void*>(gemm_pp_kernel<1>), pp_lds_bytes<1>()}, {reinterpret_cast<const void*>(gemm_ppk_kernel), PPK_LDS},
                 {reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), 65536},
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), 65536}, {reinterpret_cast<const void*>(gemm_glds256_kernel<1>), 131072},
                 {reinterpret_cast<const void*>(gemm_glds256_kernel<2>), 131072},

@@ -827,7 +827,7 @@ class Prog:
         name = "buffer_load_dwordx4" if nbytes == 16 else "buffer_load_dword"
         self.add(f"{name} {voff}, {rsrc}, {soff} offen lds", emu, "vmem_lds", [voff, rsrc, soff, M0], [])
 
-    def buffer_store_dwordx4(self, data, voff, rsrc, soff, nt=False):
+    def buffer_store_dwordx4(self, data, voff, rsrc, soff, nt=False, pol=""):
         assert data.n == 4
 
         def emu(st):
@@ -840,7 +840,8 @@ class Prog:
             buf[(off[m][:, None] + np.arange(16)[None, :])] = w.copy().view(np.uint8).reshape(-1, 16)
             st.wg.stores.append((id(buf), off[m].copy()))
             st.issue_vm(lambda: None)
-        self.add(f"buffer_store_dwordx4 {data}, {voff}, {rsrc}, {soff} offen" + (" nt" if nt else ""), emu, "vmem_store", [data, voff, rsrc, soff], [])
+        self.add(f"buffer_store_dwordx4 {data}, {voff}, {rsrc}, {soff} offen" + (" nt" if nt else "") + (" " + pol if pol else ""), emu, "vmem_store",
+                 [data, voff, rsrc, soff], [])
 
 
 # ------------------------------------------------------------------------------------------------ emulator

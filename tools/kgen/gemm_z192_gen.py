@@ -555,6 +555,8 @@ class ZGen:
             if self.sched.get("no_stage"):
                 continue
             nt = bool(self.sched.get("store_nt"))
+        pol = self.sched.get("store_pol", "")
+            pol = self.sched.get("store_pol", "")
             if self.out_blocked:
                 for i in range(3):
                     B = SETB.sub(16 * (4 * i + j), 16)
@@ -573,7 +575,7 @@ class ZGen:
                             else:
                                 p.s_add_u32(T2, T2, 1024)
                             if not self.sched.get("no_store"):
-                                p.buffer_store_dwordx4(B.sub(4 * kp, 4), VS, RS_O, T2, nt=nt)
+                                p.buffer_store_dwordx4(B.sub(4 * kp, 4), VS, RS_O, T2, nt=nt, pol=pol)
                                 self.vm_log.append("S")
                         atom(2, "vmem", st)
                 continue
@@ -612,7 +614,7 @@ class ZGen:
                             else:
                                 p.s_add_u32(T2, T2, LDC16)        # next row block: + 32 rows - 96 B
                         if not self.sched.get("no_store"):
-                            p.buffer_store_dwordx4(SETB.sub(16 * (4 * i + j) + 4 * kp, 4), VGO[r], RS_O, T2, nt=nt)
+                            p.buffer_store_dwordx4(SETB.sub(16 * (4 * i + j) + 4 * kp, 4), VGO[r], RS_O, T2, nt=nt, pol=pol)
                             self.vm_log.append("S")
                     atom(2, "vmem", st)
         return atoms
@@ -648,6 +650,7 @@ class ZGen:
         sets = [BQ, BQB]
         self.lg_log = ["F"] * 7                                    # the (unused) prefetch fragment reads of a next tile's first k-step
         nt = bool(self.sched.get("store_nt"))
+        pol = self.sched.get("store_pol", "")
 
         def bias_reads(step, i):
             for q in range(4):
@@ -689,7 +692,7 @@ class ZGen:
                         p.s_add_u32(T3, T3, T0)
                         p.s_add_u32(T2, T3, (2 * i + kp) * 1024)
                         if not self.sched.get("no_store"):
-                            p.buffer_store_dwordx4(B.sub(4 * kp, 4), VS, RS_O, T2, nt=nt)
+                            p.buffer_store_dwordx4(B.sub(4 * kp, 4), VS, RS_O, T2, nt=nt, pol=pol)
                             self.vm_log.append("S")
             return
 
@@ -738,7 +741,7 @@ class ZGen:
                 p.s_add_u32(T2, T2, LDC32)                  # next row block: 32 rows on
             for r in range(6):
                 if not self.sched.get("no_store"):
-                    p.buffer_store_dwordx4(quad(j, r), EVG[r], RS_O, T2, nt=nt)
+                    p.buffer_store_dwordx4(quad(j, r), EVG[r], RS_O, T2, nt=nt, pol=pol)
                     self.vm_log.append("S")
 
         steps = [(j, i) for j in range(4) for i in range(3)]
@@ -1089,6 +1092,9 @@ VARIANTS = {
     10: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True), out_blocked=True),     # = the product's fc1 body
     11: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, no_store=True), ablation=True),   # the product schedule without its global stores
     12: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_nt=True)),        # non-temporal epilogue stores
+    13: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_pol="sc1")),      # epilogue stores with other cache scopes: does the
+    14: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_pol="sc0 sc1")),  # end-of-kernel L2 write-back of ~25-100 MB of dirty
+    15: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_pol="sc0 sc1", store_nt=True)),   # output lines cost launch time?
 }
 
 PRODUCT_BODIES = {      # gemm_z192.hip includes gemm_z192_body_<name>.inc

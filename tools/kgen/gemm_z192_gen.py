@@ -555,7 +555,6 @@ class ZGen:
             if self.sched.get("no_stage"):
                 continue
             nt = bool(self.sched.get("store_nt"))
-        pol = self.sched.get("store_pol", "")
             pol = self.sched.get("store_pol", "")
             if self.out_blocked:
                 for i in range(3):

@@ -336,7 +336,10 @@ def ref_sam_attention(qkv, rel_h, rel_w, bias, B, S, heads, win, hd=64):
 # (48, 14) and (64, 14): window geometries the 512-px path never produces — 3 query tiles (a wave without work), 4 (one each), 2 of
 # 64 and 36 queries (key split) — for the windowed kernel's work split.
 @pytest.mark.parametrize("S,win,hd", [(32, 14, 64), (32, 32, 64), (16, 14, 64), (16, 16, 64), (48, 14, 64), (64, 14, 64),
-                                      (16, 14, 80), (16, 16, 80), (32, 14, 80), (32, 32, 80)])
+                                      (16, 14, 80), (16, 16, 80), (32, 14, 80), (32, 32, 80),
+                                      # attention_hdx's workgroup slots (window, part of four query tiles): 25 slots with 3- and 2-tile edge
+                                      # windows at S = 48, 41 slots at S = 64 (1024-px ViT-H tiles)
+                                      (48, 14, 80), (64, 14, 80)])
 def test_sam_attention(ctx, S, win, hd):
     B, heads = 2, 3
     D = heads * hd

@@ -302,7 +302,7 @@ void gemm_glds_kernel(GemmParams p) {
 // branching), the wait is the builtin.  buffer_load ... lds with the k-tile's scalar offset: no address arithmetic in the loop.
 // One workgroup per CU (NST x 32 KiB of LDS): made for layers whose tile count is below ~2 per CU anyway.
 // ---------------------------------------------------------------------------------------------------
-template <int NST>
+template <int NST, int AMODE = 0>      // AMODE 1: implicit 3 x 3 conv (a_src): the A pieces' per-lane offsets follow the k-tile's tap
 __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
     static_assert(NST == 3 || NST == 4, "ring depth");
     constexpr int BM = 128, BN = 128, TILE = BM * BK * 2, STAGE = 2 * TILE;
@@ -321,21 +321,34 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
 
     // DMA piece i (0..3) of a wave covers rows i*32 + wave*8 .. +8 of the tile, 8 rows x 128 B = 1 KiB; swizzle on the source side
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    // conv: the A resource ends with the activation grid, and a tap that leaves the image is an offset beyond it — the buffer load's
+    // range check returns the zero padding
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, AMODE == 1 ? p.M * p.lda * 2 : 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
     const int prow = lane >> 3, pc = lane & 7;
-    int aoff[4], woff[4];
+    int aoff[4], woff[4], apx[4], apy[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = i * 32 + wave * 8 + prow;
         const int c = pc ^ ((r >> 1) & 7);
-        aoff[i] = (min(m0 + r, p.M - 1) * p.lda + c * 8) * 2;
+        const int m = min(m0 + r, p.M - 1);
+        aoff[i] = (m * p.lda + c * 8) * 2;
         woff[i] = ((n0 + r) * p.ldw + c * 8) * 2;
+        apx[i] = AMODE == 1 ? m % p.conv_S : 0;
+        apy[i] = AMODE == 1 ? (m / p.conv_S) % p.conv_S : 0;
     }
 #define SRH_RING_DMA(kt, ring) { const int so_ = (kt) * (BK * 2); \
+    int tap_ = 0, dy_ = 0, dx_ = 0, ashift_ = 0; \
+    if (AMODE == 1) { tap_ = (kt) * BK / p.conv_C; dy_ = tap_ / 3 - 1; dx_ = tap_ - 3 * (tap_ / 3) - 1; \
+                      ashift_ = ((dy_ * p.conv_S + dx_) * p.lda + (kt) * BK - tap_ * p.conv_C) * 2; } \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
         char* d_ = (ring) + (i * 32 + wave * 8) * 128; \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)d_, 16, aoff[i], so_, 0, 0); \
+        if (AMODE == 1) { \
+            const bool in_ = (unsigned)(apy[i] + dy_) < (unsigned)p.conv_S && (unsigned)(apx[i] + dx_) < (unsigned)p.conv_S; \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)d_, 16, in_ ? aoff[i] + ashift_ : 0x7ffffff0, 0, 0, 0); \
+        } else { \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr)d_, 16, aoff[i], so_, 0, 0); \
+        } \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(d_ + TILE), 16, woff[i], so_, 0, 0); } }
 
     f32x16 acc[2][2];
@@ -1402,7 +1415,11 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
     if (p.N % 128 != 0 || p.K % BK != 0) return -2;
-    if (p.conv_S > 0) return p.conv_C % BK != 0 ? -2 : launch_cfg<1, 2, 2, 2, 2>(p, stream);
+    if (p.conv_S > 0) {                           // implicit 3 x 3 conv (the neck): the ring kernel with tap-following A pieces; the zero padding is
+        if (p.conv_C % BK != 0 || p.K != 9 * p.conv_C || p.splitk > 1 || (long)p.M * p.lda * 2 >= 0x7ffffff0L) return -2;      // the buffer load's range check
+        hipLaunchKernelGGL((gemm_ring_kernel<3, 1>), dim3(((p.M + 127) / 128) * (p.N / 128)), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
 #ifdef SRH_TUNING
     static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
     { int rc; if ((p.variant || env_variant) && launch_gemm_probe_variant(p, stream, p.variant ? p.variant : env_variant, &rc)) return rc; }

@@ -263,9 +263,11 @@ def test_gemm_inplace_residual(ctx):
     assert (dX.cpu() - ref).abs().max().item() < 1e-3
 
 
-def test_conv3x3(ctx):
-    B, S, Cc, N = 2, 16, 128, 128
-    g = torch.Generator().manual_seed(9)
+# (3, 32, 256, 256): the neck's shape (ViT-B tiles) with three images — taps must not cross from one image into the next;
+# (1, 64, 64, 128): one k-tile per tap, a 1024-px tile's grid
+@pytest.mark.parametrize("B,S,Cc,N", [(2, 16, 128, 128), (3, 32, 256, 256), (1, 64, 64, 128)])
+def test_conv3x3(ctx, B, S, Cc, N):
+    g = torch.Generator().manual_seed(9 + B + S)
     x = torch.randn(B, Cc, S, S, generator=g).half()
     w = (torch.randn(N, Cc, 3, 3, generator=g) * 0.05).half()
     ref = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1)          # [B,S,S,N]

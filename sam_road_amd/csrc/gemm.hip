@@ -1406,11 +1406,11 @@ static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, i
 #endif
 
 // Kernel choice by shape — the whole product dispatch:
-//   3x3 conv (neck)                                     -> register-staged implicit GEMM
+//   3x3 conv (neck)                                     -> the three-stage LDS-DMA ring kernel with tap-following A pieces (gemm_ring_kernel<3, 1>)
 //   big fp16-output layers with a bias (ViT-B blocks)   -> gemm_z192 (generated body, persistent 256 x 192 tiles, deferred epilogue)
 //   M >= 4096, N % 256 == 0, tiles fill the chip        -> 256 x 256 LDS-DMA tiles
-//   small M (ViT-L / ViT-H at 256 px)                   -> 128 x 256 tiles on the 8-wave ring kernel (+ split-K) | 128 x 160 tiles | 128 x 128
-//                                                          split-K + ordered reduce | 3-stage ring
+//   small M (ViT-L / ViT-H at 256 px)                   -> 128 x 256 tiles on the 8-wave ping-pong kernel (+ split-K, partials reduced in order by a
+//                                                          reduce pass or by the caller's next LayerNorm) | 128 x 320 | 128 x 160 | 128 x 128 split-K | 3-stage ring
 //   everything else                                     -> 128 x 128 LDS-DMA tiles, two workgroups per CU
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;

@@ -45,6 +45,9 @@ WORKLOADS = {
                  what="full SAMRoad.forward: encoder + map_decoder + sampler + TopoNet on 256 points / tile (BASELINE configs[2])"),
     "vith256": dict(version="vit_h", patch=256, batch=8, gflop=332.23 + 0.21, yaml="toponet_vith_256.yaml",
                     what="ViT-H encoder + map_decoder (BASELINE configs[4])"),
+    # not a BASELINE config: the reference's live config/toponet_vitb_1024.yaml at its own BATCH_SIZE (937.58 + 3.355 GF per tile)
+    "vitb1024": dict(version="vit_b", patch=1024, batch=4, gflop=937.58 + 3.355, yaml="toponet_vitb_1024.yaml",
+                     what="ViT-B encoder (64 x 64 tokens, global attention over 4096 keys) + map_decoder"),
 }
 
 
@@ -124,7 +127,7 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
     import torch.distributed as dist
     from sam_road_amd import _lib
     res = {}
-    for name, steps in (("full", 40), ("vith256", 40)):
+    for name, steps in (("full", 40), ("vith256", 40), ("vitb1024", 20)):
         reuse = name == "full"                  # configs[2] is the headline's model with the TopoNet branch switched on
         net, _, _, step, B, P, WL = build_workload(name, 0, rank, dev, distributed, net=net_b if reuse else None, sd=sd_b if reuse else None)
 
@@ -160,6 +163,10 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
             r["gemm"] = {"achieved_tflops": round(ach, 2), "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "launches_per_step": n // 3,
                          "avg_launch_ms": round(ms / max(n, 1), 5)}
             r["by_class_ms_per_step"] = {x["name"]: round(x["ms"] / 3, 4) for x in rows}
+            ag = [x for x in rows if x["name"] == "attn_global" and x["ms"] > 0]
+            if ag:      # the global attention on its own (algorithmic FLOPs incl. the softmax-free 4 S^4 hd convention of SURVEY App. C)
+                r["attn_global"] = {"achieved_tflops": round(sum(x["flops"] for x in ag) / (sum(x["ms"] for x in ag) * 1e-3) / 1e12, 1),
+                                    "avg_launch_ms": round(sum(x["ms"] for x in ag) / sum(x["launches"] for x in ag), 5)}
         res[name] = r
         if not reuse:
             del net, step
@@ -321,7 +328,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="tiles per step per GPU (default: the workload's BASELINE batch)")
-    ap.add_argument("--workload", default="encdec", choices=["encdec", "full", "vith256"],
+    ap.add_argument("--workload", default="encdec", choices=["encdec", "full", "vith256", "vitb1024"],
                     help="encdec: BASELINE configs[1] (headline: ViT-B 512^2 B=16, encoder + map_decoder); "
                          "full: configs[2] (the same + sampler + TopoNet, 256 points per tile = SAMRoad.forward); "
                          "vith256: configs[4] (toponet_vith_256.yaml, ViT-H 256^2 tiles, B=8, encoder + map_decoder)")

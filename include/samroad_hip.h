@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 7
+#define SRH_ABI_VERSION 8
 
 typedef enum {
     SRH_OK = 0,
@@ -35,7 +35,8 @@ typedef enum {
     SRH_ERR_UNSUPPORTED = -2,  /* configuration not built (e.g. head_dim other than 64 / 80) */
     SRH_ERR_HIP = -3,          /* HIP runtime error (text in srh_last_error) */
     SRH_ERR_MISSING_WEIGHT = -4,
-    SRH_ERR_NO_DEVICE = -5
+    SRH_ERR_NO_DEVICE = -5,
+    SRH_ERR_NONFINITE = -6     /* ABI 8: a LayerNorm pass of an EARLIER call on this context read an Inf / NaN (fp16 overflow upstream) */
 } srh_status;
 
 typedef enum { SRH_F32 = 0, SRH_F16 = 1, SRH_U8 = 2, SRH_I32 = 3, SRH_I64 = 4 } srh_dtype;
@@ -75,6 +76,14 @@ const char* srh_build_id(void);
 int srh_ctx_create(int device, srh_ctx** out);
 void srh_ctx_destroy(srh_ctx* ctx);
 const char* srh_last_error(const srh_ctx* ctx);
+/* ABI 8 — non-finite sentinel.  Inter-kernel activations are fp16; a checkpoint whose activations overflow would come out as silently
+ * wrong masks (the reference's own guards, inferencer.py:206 NaN -> -100 and :219 assert 0 <= score <= 1, only see TopoNet's output).
+ * Every LayerNorm pass of the encoder / neck / map_decoder reads each branch output anyway and flags a row whose variance is not finite
+ * (flags live in host-mapped memory: nothing is copied or synchronised in the hot loop).  The condition is reported LAZILY as
+ * SRH_ERR_NONFINITE — by the next srh_encode_decode / srh_scene_pass1 on the context, or by srh_ctx_check — with srh_last_error naming
+ * the first stage that saw it ("encoder block 7, norm2 ..."); reporting clears it.  synchronize != 0: wait for `stream` first (the
+ * answer then covers every call issued so far); 0: only what has already completed. */
+int srh_ctx_check(srh_ctx* ctx, void* stream, int synchronize);
 
 /* Packs `net.load_state_dict(ckpt["state_dict"])` + `net.to(device)` (inferencer.py:250-254):
  * fp16 MFMA operand copies of every matmul weight (conv kernels re-ordered to the GEMM K order),
@@ -111,11 +120,16 @@ int srh_toponet(srh_ctx* ctx, const srh_weights* w, const float* embeddings, con
 /* infer_toponet over the query rows of MANY tiles at once, unpadded (pass 2 of infer_one_img, inferencer.py:179-207: the reference
  * pads every batch of INFER_BATCH_SIZE tiles to its longest tile, graph_collate_fn-style; every row is scored on its own, so the
  * padding rows are pure waste — 68 k padded rows for 48 k real ones on a CityScale scene).  Rows = the concatenated per-tile point
- * lists; points f32 [R,2] tile-local (x,y); point_tile i32 [R] = index of the row's tile in `embeddings` [n,h,w,256]; pairs i32
- * [R,K,2] = (row, target row) into the flat list; valid u8 [R,K]; scores f32 [R,K] out.  srh_pass2_pack_ragged builds these. */
-int srh_toponet_ragged(srh_ctx* ctx, const srh_weights* w, const float* embeddings, const float* points,
+ * lists; embeddings [n_tiles,h,w,256]; points f32 [R,2] tile-local (x,y); point_tile i32 [R] = index of the row's tile in
+ * `embeddings` (clamped into [0, n_tiles)); pairs i32 [R,K,2] = (row, target row) into the flat list; valid u8 [R,K]; scores f32
+ * [R,K] out.  srh_pass2_pack_ragged builds these.
+ * ABI 8: tile_offsets (HOST pointer, int64 [n_tiles + 1], nullable) = the first row of every tile, from 0 to R.  With it the rows are
+ * scored in chunks of whole tiles of at most 16 384 rows (same bits: rows are independent and a pair only names rows of its own
+ * tile), so the context's workspace is bounded like the reference's INFER_BATCH_SIZE batches instead of growing with the scene;
+ * without it the call is one launch and refuses more than 65 536 rows. */
+int srh_toponet_ragged(srh_ctx* ctx, const srh_weights* w, const float* embeddings, int n_tiles, const float* points,
                        const int32_t* point_tile, const int32_t* pairs, const uint8_t* valid, int64_t R, int K,
-                       float* scores, void* stream);
+                       const int64_t* tile_offsets, float* scores, void* stream);
 
 /* scene level (pass 1 of infer_one_img, inferencer.py:79-110) ------------------------------------ */
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SRH_LIB_PATH") or os.path.join(_HERE, "libsamroad_hip.so")
 
 SRH_F32, SRH_F16, SRH_U8, SRH_I32, SRH_I64 = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 SRH_GEMM_A_BLOCKED16, SRH_GEMM_OUT_BLOCKED16 = 1, 2       # srh_op_gemm_ex flags (include/samroad_hip.h)
 
 
@@ -66,7 +66,8 @@ SYMBOLS = {
     "srh_votes_to_edges": (_I, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, _P, _P]),
     "srh_pass2_pack": (_I, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     "srh_pass2_pack_ragged": (_I, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
-    "srh_toponet_ragged": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _I, _P, _P]),
+    "srh_toponet_ragged": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_int64, _I, _P, _P, _P]),
+    "srh_ctx_check": (_I, [_P, _P, _I]),
     "srh_kdtree_knn_host": (_I, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_double, _P, _P]),
     "srh_mask_candidates": (_I, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int64, _P, C.c_int32]),
     "srh_nms_merge_points": (_I, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int32, _P, _P]),

@@ -43,9 +43,13 @@ struct srh_ctx {
     int device = 0;
     std::string err;
     // encoder / decoder workspace
-    DevBuf a0, x, xn16, delta16, delta16b, qkv16, attn16, hid16, n1, n1_16, n2, emb16, d0, d0_16, d1_16;
+    DevBuf a0, x, xn16, delta16, delta16b, qkv16, attn16, hid16, n1, n1_16, n2, emb16;
     DevBuf scores_ws, emb_ws, counter, split_ws;
     ZTileTables ztab;            // gemm_z192's tile-order tables (one bounded slab, freed with the context)
+    // non-finite sentinel: NF_SLOTS flags in host-mapped pinned memory (nf_host; nf_dev = the same bytes as the device sees them).
+    // The LayerNorm passes set flag `tag` when a row's variance is not finite (NormParams::nf) — an fp16 overflow upstream.  Nothing is
+    // copied or synchronised in the hot loop: a set flag crosses PCIe once, the host reads its own memory at the next call.
+    unsigned* nf_host = nullptr; unsigned* nf_dev = nullptr;
     // SAM MaskDecoder branch workspace
     DevBuf sd_keys, sd_keys16, sd_k16, sd_v16, sd_a16, sd_u0, sd_u0_16, sd_u1_16, sd_low, sd_tok;
     // toponet workspace
@@ -87,11 +91,13 @@ struct srh_weights {
     f16* patch_w; float* patch_b; float* pos;
     std::vector<BlockW> blocks;
     f16 *neck0_w, *neck2_w; float *neck1_g, *neck1_b, *neck3_g, *neck3_b;
-    f16 *dec0_w, *dec3_w, *dec5_w; float *dec0_b, *dec1_g, *dec1_b, *dec3_b, *dec5_b, *dec7_w, *dec7_b;
+    char* dec_frags = nullptr; float* dec_prm = nullptr;          // fused map_decoder (decoder.hip): packed MFMA fragments + f32 parameters
     f16* tp_feat_w; float* tp_feat_b;
     char* tp_stream = nullptr; float* tp_params = nullptr;       // fused trunk (topo_fused.hip)
     int tp_layers = 0;                                            // encoder layers of the trunk (0: TOPONET_VERSION no_transformer)
 };
+
+constexpr int NF_SLOTS = 128, NF_NECK = 64, NF_DECODER = 66;   // tags: 2 * block + (0 norm1 | 1 norm2), neck LN2d 64 / 65, map_decoder LN2d 66
 
 static int fail(srh_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -164,6 +170,15 @@ extern "C" int srh_ctx_create(int device, srh_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return SRH_ERR_HIP;
     srh_ctx* c = new srh_ctx();
     c->device = device;
+    void* h = nullptr; void* d = nullptr;
+    if (hipHostMalloc(&h, NF_SLOTS * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        if (h) hipHostFree(h);
+        delete c;
+        return SRH_ERR_HIP;
+    }
+    memset(h, 0, NF_SLOTS * sizeof(unsigned));
+    c->nf_host = (unsigned*)h; c->nf_dev = (unsigned*)d;
     *out = c;
     return SRH_OK;
 }
@@ -172,12 +187,13 @@ extern "C" void srh_ctx_destroy(srh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->delta16, &c->delta16b, &c->qkv16, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
-                      &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
+                      &c->emb16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
                       &c->sd_keys, &c->sd_keys16, &c->sd_k16, &c->sd_v16, &c->sd_a16, &c->sd_u0, &c->sd_u0_16, &c->sd_u1_16,
                       &c->sd_low, &c->sd_tok,
                       &c->t_feat16, &c->t_pf16, &c->t_pair16};
     for (DevBuf* b : bufs) b->release();
     c->ztab.release();
+    if (c->nf_host) hipHostFree(c->nf_host);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     delete c;
 }
@@ -185,7 +201,7 @@ extern "C" void srh_ctx_destroy(srh_ctx* c) {
 extern "C" size_t srh_ctx_device_bytes(const srh_ctx* c) {
     if (!c) return 0;
     const DevBuf* bufs[] = {&c->a0, &c->x, &c->xn16, &c->delta16, &c->delta16b, &c->qkv16, &c->attn16, &c->hid16, &c->n1, &c->n1_16, &c->n2,
-                            &c->emb16, &c->d0, &c->d0_16, &c->d1_16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
+                            &c->emb16, &c->scores_ws, &c->emb_ws, &c->counter, &c->split_ws,
                             &c->sd_keys, &c->sd_keys16, &c->sd_k16, &c->sd_v16, &c->sd_a16, &c->sd_u0, &c->sd_u0_16, &c->sd_u1_16,
                             &c->sd_low, &c->sd_tok, &c->t_feat16, &c->t_pf16, &c->t_pair16};
     size_t n = c->ztab.device_bytes();
@@ -194,6 +210,34 @@ extern "C" size_t srh_ctx_device_bytes(const srh_ctx* c) {
 }
 
 extern "C" const char* srh_last_error(const srh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+// The sentinel flags as the host sees them NOW (no synchronisation): SRH_ERR_NONFINITE + a message naming the first stage that saw an
+// Inf / NaN, flags cleared; 0 if none is set.  The reference's own guards (inferencer.py:206 NaN -> -100, :219 assert 0 <= score <= 1)
+// only look at TopoNet's output; an fp16 overflow in the encoder would otherwise come out as silently wrong masks.
+static int nonfinite_check(srh_ctx* c, const char* who) {
+    if (!c->nf_host) return 0;
+    int first = -1;
+    for (int i = 0; i < NF_SLOTS; ++i)
+        if (reinterpret_cast<volatile unsigned*>(c->nf_host)[i]) { if (first < 0) first = i; c->nf_host[i] = 0; }
+    if (first < 0) return 0;
+    std::string where;
+    if (first < NF_NECK) where = "encoder block " + std::to_string(first / 2) + (first & 1 ? ", norm2 (the block's attention branch output or its residual stream)"
+                                                                                         : ", norm1 (the previous block's MLP output, the patch embedding for block 0, or the residual stream)");
+    else if (first < NF_DECODER) where = std::string("neck LayerNorm2d ") + (first == NF_NECK ? "1 (the last block's output)" : "2");
+    else where = "map_decoder LayerNorm2d";
+    return fail(c, SRH_ERR_NONFINITE, std::string(who) + ": non-finite activations (fp16 overflow?) in an earlier call on this context, first seen by " + where +
+                                      "; the outputs of that call are invalid");
+}
+
+extern "C" int srh_ctx_check(srh_ctx* c, void* stream, int synchronize) {
+    if (!c) return SRH_ERR_BAD_ARG;
+    if (synchronize) {
+        hipSetDevice(c->device);
+        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(c, e, "srh_ctx_check");
+    }
+    return nonfinite_check(c, "srh_ctx_check");
+}
 
 // ---- weight packing --------------------------------------------------------------------------------
 namespace {
@@ -313,6 +357,72 @@ static void pack_topo_fused(Packer& pk, srh_weights* w, int nl) {
     prm(128 + (size_t)1280 * nl + 128, T + "output_proj.bias", 1);
     pk.slot(&w->tp_stream, soff);
     pk.slot(&w->tp_params, poff);
+}
+
+// Weights of the fused map_decoder (decoder.hip decode_fused_kernel; reference model.py:286-295).  A ConvTranspose2d(k2, s2) layer is a
+// per-pixel GEMM to 4 x Cout columns, n = (ky * 2 + kx) * Cout + co, W_gemm[n][ci] = w[ci][co][ky][kx]; every matrix is cut into
+// 16 (out) x 32 (in) MFMA A fragments of 1 KiB as in pack_topo_fused (lane l = row i = l & 15, k group g = l >> 4, 8 halves).  Layer 0
+// reads its input from memory (natural k order); layers 3 and 5 read C-layout tile pairs of the previous MFMA (permuted k order).
+//   frags: L0 [sub1 4][kb 8][rt 8] (64 KiB per sub1), L3 [sub2 4][kb 4][rt 4] (64 KiB), L5 [kb 2][rt 8] (16 KiB)
+//   prm  : b0[128] | ln gamma[128] | ln beta[128] | b3[64] | b5[32] | w7[8][32] (n = (ky*2+kx)*2 + class) | b7[2]
+static void pack_decoder_fused(Packer& pk, srh_weights* w) {
+    const size_t nfrag = 256 + 64 + 16, nprm = 128 * 3 + 64 + 32 + 256 + 2;
+    const size_t foff = pk.alloc(nfrag * 1024), poff = pk.alloc(nprm * 4);
+    size_t f = 0;
+    std::vector<float> wg;                                 // the layer's GEMM weight [4 * cout][cin]
+    auto load = [&](const std::string& name, int cin, int cout) -> bool {
+        const float* src = pk.get(name, (size_t)cin * cout * 4);
+        if (!src) return false;
+        wg.assign((size_t)4 * cout * cin, 0.f);
+        for (int sub = 0; sub < 4; ++sub)
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci) wg[((size_t)sub * cout + co) * cin + ci] = src[((size_t)ci * cout + co) * 4 + sub];
+        return true;
+    };
+    auto frag = [&](bool have, int ldw, int row0, int kb, bool perm) {
+        f16* o = reinterpret_cast<f16*>(pk.host.data() + foff) + f * 512;
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, g = l >> 4;
+                const int k = perm ? 32 * kb + 16 * (j >> 2) + 4 * g + (j & 3) : 32 * kb + 8 * g + j;
+                o[l * 8 + j] = have ? (f16)wg[(size_t)(row0 + i) * ldw + k] : (f16)0.f;
+            }
+        ++f;
+    };
+    {
+        const bool have = load("map_decoder.0.weight", 256, 128);
+        for (int s1 = 0; s1 < 4; ++s1)
+            for (int kb = 0; kb < 8; ++kb)
+                for (int rt = 0; rt < 8; ++rt) frag(have, 256, s1 * 128 + 16 * rt, kb, false);
+    }
+    {
+        const bool have = load("map_decoder.3.weight", 128, 64);
+        for (int s2 = 0; s2 < 4; ++s2)
+            for (int kb = 0; kb < 4; ++kb)
+                for (int rt = 0; rt < 4; ++rt) frag(have, 128, s2 * 64 + 16 * rt, kb, true);
+    }
+    {
+        const bool have = load("map_decoder.5.weight", 64, 32);
+        for (int kb = 0; kb < 2; ++kb)
+            for (int rt = 0; rt < 8; ++rt) frag(have, 64, 16 * rt, kb, true);
+    }
+    auto prm = [&](size_t at, const std::string& name, size_t n) {
+        const float* src = pk.get(name, n);
+        if (src) memcpy(pk.host.data() + poff + at * 4, src, n * 4);
+    };
+    prm(0, "map_decoder.0.bias", 128);
+    prm(128, "map_decoder.1.weight", 128);
+    prm(256, "map_decoder.1.bias", 128);
+    prm(384, "map_decoder.3.bias", 64);
+    prm(448, "map_decoder.5.bias", 32);
+    if (const float* src = pk.get("map_decoder.7.weight", 32 * 2 * 4)) {
+        float* o = reinterpret_cast<float*>(pk.host.data() + poff) + 480;
+        for (int nn = 0; nn < 8; ++nn)
+            for (int ci = 0; ci < 32; ++ci) o[nn * 32 + ci] = src[(ci * 2 + (nn & 1)) * 4 + (nn >> 1)];
+    }
+    prm(736, "map_decoder.7.bias", 2);
+    pk.slot(&w->dec_frags, foff);
+    pk.slot(&w->dec_prm, poff);
 }
 
 // SAM MaskDecoder branch: prompt_encoder.* / mask_decoder.* (fork key names; oracle/sam_decoder.py).  The random-Fourier
@@ -500,35 +610,7 @@ static int pack_impl(srh_ctx* c, const srh_model_cfg* cfg, const srh_named_tenso
     if (cfg->use_sam_decoder) {
         pack_sam_decoder(pk, w);
     } else {
-        // map_decoder: ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM weight [n = (ky*2+kx)*Cout + co][ci]
-        auto convt = [&](f16** dst, float** bdst, const std::string& idx, int cin, int cout) {
-            pk.put_f16(dst, "map_decoder." + idx + ".weight", (size_t)cin * cout * 4, (size_t)4 * cout * cin,
-                       [cin, cout](size_t i) {
-                           const size_t nidx = i / cin, ci = i % cin, sub = nidx / cout, co = nidx % cout;
-                           return (long)((ci * cout + co) * 4 + sub);
-                       });
-            const float* bsrc = pk.get("map_decoder." + idx + ".bias", cout);
-            const size_t off = pk.alloc((size_t)4 * cout * 4);
-            if (bsrc)
-                for (int r = 0; r < 4; ++r) memcpy(pk.host.data() + off + (size_t)r * cout * 4, bsrc, (size_t)cout * 4);
-            pk.slot(bdst, off);
-        };
-        convt(&w->dec0_w, &w->dec0_b, "0", 256, 128);
-        pk.put_f32(&w->dec1_g, "map_decoder.1.weight", 128);
-        pk.put_f32(&w->dec1_b, "map_decoder.1.bias", 128);
-        convt(&w->dec3_w, &w->dec3_b, "3", 128, 64);
-        convt(&w->dec5_w, &w->dec5_b, "5", 64, 32);
-        {
-            const float* src = pk.get("map_decoder.7.weight", 32 * 2 * 4);
-            const size_t off = pk.alloc(8 * 32 * 4);
-            if (src) {
-                float* o = reinterpret_cast<float*>(pk.host.data() + off);
-                for (int nn = 0; nn < 8; ++nn)
-                    for (int ci = 0; ci < 32; ++ci) o[nn * 32 + ci] = src[(ci * 2 + (nn & 1)) * 4 + (nn >> 1)];
-            }
-            pk.slot(&w->dec7_w, off);
-            pk.put_f32(&w->dec7_b, "map_decoder.7.bias", 2);
-        }
+        pack_decoder_fused(pk, w);
     }
 
     // TopoNet
@@ -611,9 +693,6 @@ static int ensure_encoder_ws(srh_ctx* c, const srh_weights* w, int B) {
     rc |= c->n1_16.ensure(T * 256 * 2);
     rc |= c->n2.ensure(T * 256 * 4);
     rc |= c->emb16.ensure(T * 256 * 2);
-    rc |= c->d0.ensure(T * 512 * 4);
-    rc |= c->d0_16.ensure(T * 512 * 2);
-    rc |= c->d1_16.ensure(T * 1024 * 2);
     return rc ? fail(c, SRH_ERR_HIP, "workspace allocation failed") : 0;
 }
 
@@ -725,12 +804,6 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
     TRY(ensure_encoder_ws(c, w, B));
     pp.B = B; pp.P = w->cfg.patch_size; pp.out = c->a0.as<f16>();
     TRYK(c, "patch_im2col", 0, (double)T * 768 * (pp.src_is_u8 ? 3 : 6), s, launch_patch_im2col(pp, s));
-    {
-        GemmParams g;
-        g.A = c->a0.as<f16>(); g.lda = 768; g.W = w->patch_w; g.ldw = 768; g.M = T; g.N = D; g.K = 768;
-        g.bias = w->patch_b; g.pos = w->pos; g.pos_rows = S * S; g.out_f32 = c->x.as<float>(); g.ldc = D;
-        TRY(gemm(c, "gemm_patch_embed", g, s));
-    }
     // Residual stream: x stays fp32.  Where the persistent z192 GEMM applies (gemm_z192.hip: fp16 output only), proj / fc2
     // write their branch output (bias included) as fp16 into delta16 and the NEXT LayerNorm pass folds "x += delta" into
     // its read of x — the same HBM bytes as the GEMM-epilogue residual add, but moved out of the GEMM's exposed epilogue
@@ -742,7 +815,24 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
     // Small-M models (ViT-H / ViT-L at 256 px): fc2 runs with split-K, and instead of a reduce pass its f32 partials stay in the
     // workspace for the next LayerNorm pass (or the neck's cast) to fold — x += (slice 0 + slice 1 + ...) + bias, the reduce kernel's
     // order, same bits — one launch and one round trip of x less per block.
-    bool pend_a = false, pend_b = false;                  // delta16 (proj) / delta16b (fc2) hold a branch output not yet added to x
+    // Patch embedding: where z192 applies (ViT-B widths, enough tiles) it is just another fp16 branch output — conv + bias into delta16 —
+    // and block 0's first LayerNorm pass computes the initial residual x = pos_embed[token] + delta16 (a row-modulo read of the
+    // [S*S, D] table, NormParams::x_period) and writes x: the proj-shaped GEMM takes 22 instead of 51 us on the f32 + pos epilogue.
+    bool pend_a = false, pend_b = false;                  // delta16 (patch embed / proj) / delta16b (fc2) hold a branch output not yet added to x
+    bool x_is_pos = false;                                // x has not been written yet: its value is pos_embed (block 0's first pass)
+    {
+        GemmParams g;
+        g.A = c->a0.as<f16>(); g.lda = 768; g.W = w->patch_w; g.ldw = 768; g.M = T; g.N = D; g.K = 768; g.bias = w->patch_b;
+        GemmParams gz = g;
+        gz.out_f16 = c->delta16.as<f16>(); gz.ldc16 = D;
+        if (!w->blocks.empty() && z192_preferred(gz)) {
+            TRY(gemm(c, "gemm_patch_embed", gz, s));
+            pend_a = true; x_is_pos = true;
+        } else {
+            g.pos = w->pos; g.pos_rows = S * S; g.out_f32 = c->x.as<float>(); g.ldc = D;
+            TRY(gemm(c, "gemm_patch_embed", g, s));
+        }
+    }
     int pend_slices = 0; const float* pend_bias = nullptr; // split-K partials of the last branch GEMM wait in c->split_ws
     auto branch_gemm = [&](const char* cls, const f16* A, int lda, const f16* W, int K, const float* bias, bool second, int a_blocked = 0) -> int {
         GemmParams gq;
@@ -751,19 +841,22 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         if (z192_preferred(gq)) { (second ? pend_b : pend_a) = true; return gemm(c, cls, gq, s); }
         GemmParams gp = gq;
         gp.out_f16 = nullptr; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
-        if (const int sk = gemm_splitk_factor(gp); sk > 1 && bias && (D == 1024 || D == 1280) && !pend_slices) {
+        if (const int sk = gemm_splitk_factor(gp); sk > 1 && bias && (D == 1024 || D == 1280) && !pend_slices && !pend_a && !pend_b) {
             gp.defer_reduce = 1;
             pend_slices = sk; pend_bias = bias;
         }
         return gemm(c, cls, gp, s);
     };
-    auto fold_pending = [&](NormParams& ln, int& reads) {  // what the pass has to add to x before normalising / casting
+    auto fold_pending = [&](NormParams& ln, int& reads) -> int {  // what the pass has to add to x before normalising / casting
+        if (pend_slices && (pend_a || pend_b))            // never both: the fp16 branch would be dropped (branch_gemm defers only when neither is pending)
+            return fail(c, SRH_ERR_HIP, "internal: split-K partials and an fp16 branch output pending at the same LayerNorm pass");
         if (pend_slices) {
             ln.slices = c->split_ws.as<float>(); ln.nslices = pend_slices; ln.slice_stride = (size_t)T * D; ln.slice_bias = pend_bias;
             reads = 2 * pend_slices;                      // in units of 2 bytes per element, as the fp16 branches
         } else if (pend_a && pend_b) { ln.delta16 = c->delta16.as<f16>(); ln.delta16b = c->delta16b.as<f16>(); reads = 2; }
         else if (pend_a) { ln.delta16 = c->delta16.as<f16>(); reads = 1; }
         else if (pend_b) { ln.delta16 = c->delta16b.as<f16>(); reads = 1; }
+        return 0;
     };
     bool defer_x = false;                                 // both branch GEMMs of the blocks take z192 (same shapes in every block)
     {
@@ -775,20 +868,23 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         defer_x = !w->blocks.empty() && z192_preferred(gq) && z192_preferred(g2);
     }
     // a LayerNorm pass over x (+ pending branches).  write_x: fold the pending branches into x for good.
-    auto block_ln = [&](const float* gamma, const float* beta, bool write_x) -> int {
+    auto block_ln = [&](const float* gamma, const float* beta, bool write_x, int nf_tag) -> int {
         NormParams ln;
         ln.x = c->x.as<float>(); ln.M = T; ln.D = D; ln.eps = 1e-6f; ln.out_f16 = c->xn16.as<f16>();
-        ln.gamma = gamma; ln.beta = beta;
+        ln.gamma = gamma; ln.beta = beta; ln.nf = c->nf_dev; ln.nf_tag = std::min(nf_tag, NF_NECK - 1);
+        if (x_is_pos) { ln.x = w->pos; ln.x_period = S * S; }
         int reads = 0;
-        fold_pending(ln, reads);
-        const bool wr = (write_x || pend_slices) && reads > 0;   // partials cannot wait: the next split-K GEMM overwrites the workspace
+        TRY(fold_pending(ln, reads));
+        const bool wr = (write_x || pend_slices || x_is_pos) && reads > 0;   // partials cannot wait: the next split-K GEMM overwrites the workspace
         ln.x_out = wr ? c->x.as<float>() : nullptr;
         TRYK(c, "layernorm", 0, (double)T * D * (4 + 2 + 2 * reads + (wr ? 4 : 0)), s, launch_layernorm(ln, s));
-        if (wr) { pend_a = pend_b = false; pend_slices = 0; }
+        if (wr) { pend_a = pend_b = false; pend_slices = 0; x_is_pos = false; }
         return 0;
     };
+    int blk = -1;
     for (const BlockW& b : w->blocks) {
-        TRY(block_ln(b.ln1_g, b.ln1_b, true));
+        ++blk;
+        TRY(block_ln(b.ln1_g, b.ln1_b, true, 2 * blk));
         GemmParams g;
         g.A = c->xn16.as<f16>(); g.lda = D; g.W = b.qkv_w; g.ldw = D; g.M = T; g.N = 3 * D; g.K = D;
         g.bias = b.qkv_b; g.out_f16 = c->qkv16.as<f16>(); g.ldc16 = 3 * D;
@@ -800,7 +896,7 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         ap.scale = 1.0f / sqrtf((float)hd);
         TRYK(c, b.win == S ? "attn_global" : "attn_window", attn_flops(B, S, heads, hd, b.win), 0, s, launch_attention(ap, s));
         TRY(branch_gemm("gemm_proj", c->attn16.as<f16>(), D, b.proj_w, D, b.proj_b, false));
-        TRY(block_ln(b.ln2_g, b.ln2_b, !defer_x));
+        TRY(block_ln(b.ln2_g, b.ln2_b, !defer_x, 2 * blk + 1));
         GemmParams g1;
         g1.A = c->xn16.as<f16>(); g1.lda = D; g1.W = b.fc1_w; g1.ldw = D; g1.M = T; g1.N = 4 * D; g1.K = D;
         g1.bias = b.fc1_b; g1.act = 1; g1.out_f16 = c->hid16.as<f16>(); g1.ldc16 = 4 * D;
@@ -823,7 +919,7 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         NormParams cast;
         cast.x = c->x.as<float>(); cast.M = T; cast.D = D; cast.out_f16 = c->xn16.as<f16>();
         int reads = 0;                                               // the last block's branch outputs, if still pending
-        fold_pending(cast, reads);
+        TRY(fold_pending(cast, reads));
         TRYK(c, "layernorm", 0, (double)T * D * (6 + 2 * reads), s, launch_layernorm(cast, s));
         GemmParams g;
         g.A = c->xn16.as<f16>(); g.lda = D; g.W = w->neck0_w; g.ldw = D; g.M = T; g.N = 256; g.K = D;
@@ -831,39 +927,25 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         TRY(gemm(c, "gemm_neck", g, s));
         NormParams ln;
         ln.x = c->n1.as<float>(); ln.M = T; ln.D = 256; ln.eps = 1e-6f; ln.gamma = w->neck1_g; ln.beta = w->neck1_b;
-        ln.out_f16 = c->n1_16.as<f16>();
+        ln.out_f16 = c->n1_16.as<f16>(); ln.nf = c->nf_dev; ln.nf_tag = NF_NECK;
         TRYK(c, "layernorm", 0, (double)T * 256 * 6, s, launch_layernorm(ln, s));
         GemmParams g3;
         g3.A = c->n1_16.as<f16>(); g3.lda = 256; g3.W = w->neck2_w; g3.ldw = 2304; g3.M = T; g3.N = 256; g3.K = 2304;
         g3.conv_S = S; g3.conv_C = 256; g3.out_f32 = c->n2.as<float>(); g3.ldc = 256;
         TRY(gemm(c, "gemm_neck", g3, s));
         ln.x = c->n2.as<float>(); ln.gamma = w->neck3_g; ln.beta = w->neck3_b;
-        ln.out_f16 = c->emb16.as<f16>(); ln.out_f32 = emb;
+        ln.out_f16 = c->emb16.as<f16>(); ln.out_f32 = emb; ln.nf_tag = NF_NECK + 1;
         TRYK(c, "layernorm", 0, (double)T * 256 * 10, s, launch_layernorm(ln, s));
     }
     if (!logits && !scores) return 0;
     if (w->cfg.use_sam_decoder) return sam_decode(c, w, B, emb, logits, scores, s);
-    // map_decoder: 3 per-pixel GEMMs (ConvT k2 s2) + LN2d/GELU, then the fused 32->2 tail
+    // map_decoder: all four ConvT layers + LayerNorm2d + GELUs + sigmoid + scatter in ONE kernel (decoder.hip), 8 MB in, the masks out
     {
-        GemmParams g;
-        g.A = c->emb16.as<f16>(); g.lda = 256; g.W = w->dec0_w; g.ldw = 256; g.M = T; g.N = 512; g.K = 256;
-        g.bias = w->dec0_b; g.out_f32 = c->d0.as<float>(); g.ldc = 512;
-        TRY(gemm(c, "gemm_decoder", g, s));
-        NormParams ln;
-        ln.x = c->d0.as<float>(); ln.M = 4 * T; ln.D = 128; ln.eps = 1e-6f; ln.gamma = w->dec1_g; ln.beta = w->dec1_b;
-        ln.act = 1; ln.out_f16 = c->d0_16.as<f16>();
-        TRYK(c, "layernorm", 0, (double)T * 512 * 6, s, launch_layernorm(ln, s));
-        GemmParams g1;
-        g1.A = c->d0_16.as<f16>(); g1.lda = 128; g1.W = w->dec3_w; g1.ldw = 128; g1.M = 4 * T; g1.N = 256; g1.K = 128;
-        g1.bias = w->dec3_b; g1.act = 1; g1.out_f16 = c->d1_16.as<f16>(); g1.ldc16 = 256;
-        TRY(gemm(c, "gemm_decoder", g1, s));
-        {       // ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + scatter in one register-resident kernel
-            DecodeTailParams tp;
-            tp.x = c->d1_16.as<f16>(); tp.w5 = w->dec5_w; tp.b5 = w->dec5_b; tp.w7 = w->dec7_w; tp.b7 = w->dec7_b;
-            tp.B = B; tp.S = S; tp.logits = logits; tp.scores = scores;
-            TRYK(c, "decode_tail", 2.0 * T * 16 * (64 * 128 + 4 * 32 * 8), (double)T * 16 * 128 + (double)T * 64 * ((logits ? 32 : 0) + (scores ? 32 : 0)), s,
-                 launch_decode_tail(tp, s));
-        }
+        DecodeFusedParams dp;
+        dp.emb16 = c->emb16.as<f16>(); dp.frags = w->dec_frags; dp.prm = w->dec_prm; dp.B = B; dp.S = S;
+        dp.logits = logits; dp.scores = scores; dp.nf = c->nf_dev; dp.nf_tag = NF_DECODER;
+        const double fl = 2.0 * T * (256.0 * 512 + 4 * 128.0 * 256 + 16 * 64.0 * 128 + 64 * 32.0 * 8);
+        TRYK(c, "map_decoder", fl, (double)T * 512 + (double)T * 256 * ((logits ? 8 : 0) + (scores ? 8 : 0)), s, launch_decode_fused(dp, s));
     }
     return 0;
 }
@@ -872,6 +954,7 @@ extern "C" int srh_encode_decode(srh_ctx* c, const srh_weights* w, const void* r
                                  float* mask_logits, float* mask_scores, float* embeddings, void* stream) {
     if (!c || !w || !rgb || !embeddings || B <= 0) return fail(c, SRH_ERR_BAD_ARG, "srh_encode_decode: bad argument");
     if (rgb_dtype != SRH_F32 && rgb_dtype != SRH_U8) return fail(c, SRH_ERR_BAD_ARG, "rgb dtype must be f32 or u8");
+    TRY(nonfinite_check(c, "srh_encode_decode"));          // lazily: what an EARLIER call's LayerNorm passes flagged (no sync here)
     hipSetDevice(c->device);
     PatchParams pp;
     pp.src = rgb; pp.src_is_u8 = rgb_dtype == SRH_U8;
@@ -881,7 +964,7 @@ extern "C" int srh_encode_decode(srh_ctx* c, const srh_weights* w, const void* r
 // ---- TopoNet --------------------------------------------------------------------------------------------
 static int toponet_impl(srh_ctx* c, const srh_weights* w, const float* embeddings, const void* points,
                         int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
-                        int Ns, int K, float* logits, float* scores, const int* point_tile, void* stream) {
+                        int Ns, int K, float* logits, float* scores, const int* point_tile, int n_tiles, long pair_base, void* stream) {
     if (!c || !w || !embeddings || !points || !pairs || !valid) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet: null argument");
     if (B <= 0 || N < 0 || Ns < 0) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet: bad sizes");
     if (K != 16) return fail(c, SRH_ERR_UNSUPPORTED, "n_pairs must be 16 (MAX_NEIGHBOR_QUERIES)");
@@ -900,7 +983,7 @@ static int toponet_impl(srh_ctx* c, const srh_weights* w, const float* embedding
     SampleParams sp;
     sp.emb = embeddings; sp.points = points; sp.points_i64 = points_dtype == SRH_I64; sp.B = B; sp.N = N;
     sp.h = w->S; sp.w = w->S; sp.C = 256; sp.patch = (float)w->cfg.patch_size; sp.out_f16 = c->t_feat16.as<f16>();
-    sp.point_tile = point_tile;
+    sp.point_tile = point_tile; sp.n_tiles = n_tiles;
     TRYK(c, "bilinear_sample", 0, (double)NP * 256 * 18, s, launch_sample(sp, s));
     GemmParams g;
     g.A = c->t_feat16.as<f16>(); g.lda = 256; g.W = w->tp_feat_w; g.ldw = 256; g.M = (int)NP; g.N = 128; g.K = 256;
@@ -909,7 +992,7 @@ static int toponet_impl(srh_ctx* c, const srh_weights* w, const float* embedding
     PairGatherParams pg;
     pg.pf = c->t_pf16.as<f16>(); pg.points = points; pg.points_i64 = points_dtype == SRH_I64;
     pg.pairs = pairs; pg.pairs_i64 = pairs_dtype == SRH_I64; pg.B = B; pg.N = N; pg.Ns = Ns; pg.Kp = K;
-    pg.zero_offset = w->cfg.toponet_version == 1; pg.out = c->t_pair16.as<f16>(); pg.ld = 320;
+    pg.zero_offset = w->cfg.toponet_version == 1; pg.out = c->t_pair16.as<f16>(); pg.ld = 320; pg.index_base = pair_base;
     TRYK(c, "pair_gather", 0, (double)R * (512 + 640), s, launch_pair_gather(pg, s));
     {
         // pair_proj + encoder layers + output_proj in one register-resident kernel (topo_fused.hip)
@@ -925,18 +1008,42 @@ static int toponet_impl(srh_ctx* c, const srh_weights* w, const float* embedding
 extern "C" int srh_toponet(srh_ctx* c, const srh_weights* w, const float* embeddings, const void* points,
                            int points_dtype, const void* pairs, int pairs_dtype, const uint8_t* valid, int B, int N,
                            int Ns, int K, float* logits, float* scores, void* stream) {
-    return toponet_impl(c, w, embeddings, points, points_dtype, pairs, pairs_dtype, valid, B, N, Ns, K, logits, scores, nullptr, stream);
+    return toponet_impl(c, w, embeddings, points, points_dtype, pairs, pairs_dtype, valid, B, N, Ns, K, logits, scores, nullptr, 0, 0, stream);
 }
 
 // The query rows of MANY tiles in one call, without padding every tile to the longest one of its batch: rows are the concatenated
 // per-tile point lists (srh_pass2_pack_ragged), every point names the tile whose embeddings it samples, pairs index the flat list.
 // The sampler, feature_proj, pair gather and the fused trunk treat every row on its own, so the scores are those of srh_toponet.
-extern "C" int srh_toponet_ragged(srh_ctx* c, const srh_weights* w, const float* embeddings, const float* points,
+extern "C" int srh_toponet_ragged(srh_ctx* c, const srh_weights* w, const float* embeddings, int n_tiles, const float* points,
                                   const int32_t* point_tile, const int32_t* pairs, const uint8_t* valid, int64_t R, int K,
-                                  float* scores, void* stream) {
-    if (!point_tile) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: null argument");
-    if (R < 0 || R * (int64_t)K > 0x7fffffffLL / 2) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: bad row count");
-    return toponet_impl(c, w, embeddings, points, SRH_F32, pairs, SRH_I32, valid, 1, (int)R, (int)R, K, nullptr, scores, point_tile, stream);
+                                  const int64_t* tile_offsets, float* scores, void* stream) {
+    if (!point_tile || !scores) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: null argument");
+    if (n_tiles <= 0) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: n_tiles must be the number of tiles in `embeddings`");
+    if (R < 0 || K != 16) return fail(c, R < 0 ? SRH_ERR_BAD_ARG : SRH_ERR_UNSUPPORTED, "srh_toponet_ragged: bad row count / n_pairs must be 16");
+    // Workspace bound (the reference's pass 2 is bounded by INFER_BATCH_SIZE, inferencer.py:179-207): with the tiles' row offsets the
+    // scene is scored in chunks of whole tiles of at most RAGGED_CHUNK_ROWS rows — rows are independent and a pair only names rows of
+    // its own tile, so the chunks' scores are those of the one launch, bit for bit — and the pair workspace stays below ~210 MB
+    // however large the scene (it grew with the scene before: 0.6 GB for a 48 k-row CityScale scene, ~10 GB for an 8192^2 one).
+    // Without offsets the caller's rows go through ONE launch and must fit the same bound.
+    constexpr int64_t RAGGED_CHUNK_ROWS = 16384;
+    if (!tile_offsets) {
+        if (R > 4 * RAGGED_CHUNK_ROWS) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: more than 65536 rows need tile_offsets (chunked at tile boundaries)");
+        return toponet_impl(c, w, embeddings, points, SRH_F32, pairs, SRH_I32, valid, 1, (int)R, (int)R, K, nullptr, scores, point_tile, n_tiles, 0, stream);
+    }
+    if (tile_offsets[0] != 0 || tile_offsets[n_tiles] != R) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: tile_offsets must run from 0 to R");
+    for (int t = 0; t < n_tiles; ++t)
+        if (tile_offsets[t + 1] < tile_offsets[t]) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: tile_offsets must ascend");
+    for (int ta = 0; ta < n_tiles;) {
+        int tb = ta + 1;                                                          // at least one tile (a tile above the bound is its own chunk)
+        while (tb < n_tiles && tile_offsets[tb + 1] - tile_offsets[ta] <= RAGGED_CHUNK_ROWS) ++tb;
+        const int64_t r0 = tile_offsets[ta], n = tile_offsets[tb] - r0;
+        if (n > 0x7fffffffLL / (2 * K)) return fail(c, SRH_ERR_BAD_ARG, "srh_toponet_ragged: a single tile has too many rows");
+        if (n > 0)
+            TRY(toponet_impl(c, w, embeddings, points + 2 * r0, SRH_F32, pairs + 2 * (int64_t)K * r0, SRH_I32, valid + (int64_t)K * r0, 1, (int)n, (int)n,
+                             K, nullptr, scores + (int64_t)K * r0, point_tile + r0, n_tiles, (long)r0, stream));
+        ta = tb;
+    }
+    return 0;
 }
 
 // ---- scene level ------------------------------------------------------------------------------------------
@@ -946,6 +1053,7 @@ extern "C" int srh_scene_pass1(srh_ctx* c, const srh_weights* w, const uint8_t* 
     if (!c || !w || !scene || !tile_xy || !canvas_kp || !canvas_road || !embeddings_all)
         return fail(c, SRH_ERR_BAD_ARG, "srh_scene_pass1: null argument");
     if (n_tiles < 0 || B <= 0 || S < w->cfg.patch_size) return fail(c, SRH_ERR_BAD_ARG, "srh_scene_pass1: bad sizes");
+    TRY(nonfinite_check(c, "srh_scene_pass1"));
     hipSetDevice(c->device);
     hipStream_t s = (hipStream_t)stream;
     const int P = w->cfg.patch_size;

@@ -31,10 +31,13 @@ template <int WIN> struct Geom;
 template <> struct Geom<14> { static constexpr int KPT = 28, RPT = 2, NT = 7, WP = 16; };
 template <> struct Geom<16> { static constexpr int KPT = 32, RPT = 2, NT = 8, WP = 16; };
 template <> struct Geom<32> { static constexpr int KPT = 32, RPT = 1, NT = 32, WP = 32; };
+// 64 x 64 (the global window of 1024-px tiles): a key tile is HALF a window row, a ring stage (two tiles) one whole row — the
+// lane's rel_w values differ between the even and the odd tile of a stage (QState::relw / relw_b), rel_h is one scalar per stage
+template <> struct Geom<64> { static constexpr int KPT = 32, RPT = 1, NT = 128, WP = 64; };
 
 // local MFMA row i of a key tile -> (row-in-tile, col) of the window
 template <int WIN> __device__ __forceinline__ void tile_rc(int i, int& r, int& c) {
-    if (WIN == 32) { r = 0; c = i; }
+    if (WIN >= 32) { r = 0; c = i; }
     else if (WIN == 16) { r = i >> 4; c = i & 15; }
     else { r = i >= 14; c = i - 14 * r; }
 }
@@ -42,6 +45,7 @@ template <int WIN> __device__ __forceinline__ void tile_rc(int i, int& r, int& c
 struct QState {
     f16x8 q[4];        // B fragments of the lane's query, 4 k-steps of 16
     f32x16 relw;       // rel_w / scale at the lane's 16 keys of a tile (tile-invariant): the S^T MFMA chain's C operand
+    f32x16 relw_b;     // 64 x 64 window only: the same for the odd tile of a stage (window columns 32..63); unused (no registers) otherwise
     float m, l;        // running max (raw units) and this half's partial row sum
     f32x16 o[2];       // O^T accumulators, d tiles 0..31 / 32..63
 };
@@ -68,7 +72,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // WIN 14: keys 0..13 / 14..27 -> r < 6 row 0, r = 6, 7 row `half`, r = 8..11 row 1, r >= 12: row 1 (half 0) / no key (half 1)
 template <int WIN>
 __device__ __forceinline__ float tile_max(const f32x16& s, float rh0, float rh1, int half) {
-    if (WIN == 32) {
+    if (WIN >= 32) {
         float m = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m = fmaxf(m, s[r]);
@@ -96,7 +100,7 @@ template <int WIN>
 __device__ __forceinline__ void tile_exp(const f32x16& s, float rh0, float rh1, float m_new, float c_exp, int half,
                                          f16x8 (&pb)[2], f32x2& sum2) {
     const float mc = -m_new * c_exp;
-    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = WIN == 32 ? mc0 : fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
+    const float mc0 = fmaf(rh0, c_exp, mc), mc1 = WIN >= 32 ? mc0 : fmaf(rh1, c_exp, mc), mcm = WIN == 14 ? (half ? mc1 : mc0) : mc0;
     const float mct = WIN == 14 ? (half ? -INFINITY : mc1) : mc1;  // r >= 12: exp2(-inf) = 0 for the rows that are not keys
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -104,7 +108,7 @@ __device__ __forceinline__ void tile_exp(const f32x16& s, float rh0, float rh1, 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int rr = r + e;
-            const float ad = WIN == 32 ? mc0 : WIN == 16 ? (rr >= 8 ? mc1 : mc0) : (rr < 6 ? mc0 : rr < 8 ? mcm : rr < 12 ? mc1 : mct);
+            const float ad = WIN >= 32 ? mc0 : WIN == 16 ? (rr >= 8 ? mc1 : mc0) : (rr < 6 ? mc0 : rr < 8 ? mcm : rr < 12 ? mc1 : mct);
             pv[e] = __builtin_amdgcn_exp2f(fmaf(s[rr], c_exp, ad));   // raw v_exp_f32: exp2(-inf) = 0
             pb[rr >> 3][rr & 7] = (f16)pv[e];
         }
@@ -156,7 +160,7 @@ __device__ __forceinline__ void load_query(QState& st, const AttnParams& p, size
 // floats).  The w table goes first: its 16 per-lane values (tile-invariant) are read back into st.relw, then the same
 // buffer is overwritten with the h table, which the key loop reads one or two scalars per tile.
 template <int WIN, int STRIDE>
-__device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, int qy, int qx, float* buf, const char* tbl_lds, int lane) {
+__device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, int qy, int qx, float* buf, const char* tbl_w, const char* tbl_h, int lane) {
     constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
     static_assert(STRIDE > WIN, "slot WIN of a row is the dump slot");
     const int half = lane >> 5, row = lane & 31;
@@ -169,12 +173,12 @@ __device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, in
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // A operand: table rows j = 32 jt + (lane & 31), staged in LDS in the K-tile format (tile pass * NTJ + jt; rows past the table's
+            // A operand: table rows j = 32 jt + (lane & 31), staged in LDS in the K-tile format (tile jt of tbl_w / tbl_h; rows past the table's
             // end hold a copy of its last row: their products land in the dump slot).  They used to be read straight from L2 — sixteen
             // 16-byte loads per lane that touch 32 table rows each, ~87 ticks of the CU's address path per instruction; the staged form
             // costs the workgroup 2 NTJ x 4 LDS-DMA pieces in all (profiles/r05_attention_global.txt)
             f16x8 a[4];
-            read_kfrag(a, tbl_lds + (pass * NTJ + jt) * 4096, lane);
+            read_kfrag(a, (pass == 0 ? tbl_w : tbl_h) + jt * 4096, lane);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mfma32(a[ks], st.q[ks], acc);
             // P^T[j, q] -> rel[q][k = qc - j + WIN - 1]: one subtract, one unsigned min and an unconditional write per element (k < 0
@@ -194,6 +198,7 @@ __device__ __forceinline__ void fused_relpos(QState& st, const AttnParams& p, in
                 int rr, cc;
                 tile_rc<WIN>(mfma32_row(r, lane), rr, cc);
                 st.relw[r] = (cc < WIN) ? buf[row * STRIDE + cc] : 0.f;
+                if (WIN == 64) st.relw_b[r] = buf[row * STRIDE + 32 + cc];
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -333,7 +338,7 @@ __device__ __forceinline__ void attn_tile2(QState& st, const f16x8 (&kfa)[4], co
                                               int vb0, int vb1, float rh0a, float rh1a, float rh0b, float rh1b, float c_exp, int lane) {
     const int half = lane >> 5;
     f32x16 sa = mfma32(kfa[0], st.q[0], st.relw);
-    f32x16 sb = mfma32(kfb[0], st.q[0], st.relw);
+    f32x16 sb = mfma32(kfb[0], st.q[0], WIN == 64 ? st.relw_b : st.relw);
 #pragma unroll
     for (int ks = 1; ks < 4; ++ks) { sa = mfma32(kfa[ks], st.q[ks], sa); sb = mfma32(kfb[ks], st.q[ks], sb); }
     f16x8 vfa[2][2], vfb[2][2];
@@ -868,35 +873,48 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 4096), 16, ko, so_ + 32 * ldb, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 8192), 16, vo, so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(d_ + 12288), 16, vo, so_ + 32 * ldb, 0, 0); }
-    {   // the two rel-pos tables into ring1 in the K-tile format (2 NTJ tiles of 4 KiB: ring1 is exactly that big for the 32 x 32 window; K / V
-        // stage 1 overwrites it behind stage 0's barrier, which every wave passes after its rel-pos): wave w moves rows 8 w .. 8 w + 7 of a tile
-        constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
-        static_assert(2 * NTJ * 4096 <= STAGE, "the tables are staged in one ring stage");
+    // the two rel-pos tables in the K-tile format (NTJ tiles of 4 KiB each): wave w moves rows 8 w .. 8 w + 7 of a tile.  Up to the 32 x 32
+    // window both fit ring1 (K / V stage 1 overwrites it behind stage 0's barrier, which every wave passes after its rel-pos) and stage 0
+    // of the K / V stream flies under the prologue; the 64 x 64 window's tables (127 rows each) fill BOTH ring stages — w in ring1, h in
+    // ring0 — and the K / V stream starts behind the rel-pos (one exposed stage of 64)
+    constexpr int NTJ = (2 * WIN - 1 + 31) / 32;
+    constexpr bool TBL2 = 2 * NTJ * 4096 > STAGE;
+    static_assert(NTJ * 4096 <= STAGE, "one table per ring stage at most");
+    {
         typedef const __attribute__((address_space(1))) void* glb_ptr;
 #pragma unroll
         for (int tt = 0; tt < 2 * NTJ; ++tt) {
             const int j = min((tt % NTJ) * 32 + r, 2 * WIN - 2);
             const f16* src = (tt < NTJ ? p.table_w : p.table_h) + (size_t)j * HD + (cpos ^ ((r >> 1) & 7)) * 8;
-            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(ring1 + tt * 4096 + wave * 1024), 16, 0, 0);
+            char* dst = TBL2 ? (tt < NTJ ? ring1 : ring0) + (tt % NTJ) * 4096 : ring1 + tt * 4096;
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(dst + wave * 1024), 16, 0, 0);
         }
     }
-    SRH_DMA_STAGE(0, ring0)                                        // in flight under the query loads and the rel-pos prologue
+    if constexpr (!TBL2) SRH_DMA_STAGE(0, ring0)                   // in flight under the query loads and the rel-pos prologue
 
     const int qi = qb * 128 + wave * 32 + (lane & 31);
     const size_t tok = tok0 + qi;
     QState st;
     load_query<WIN>(st, p, tok, head, lane);
     float* rh = rh_lds + wave * 32 * (WP + 1);
-    __builtin_amdgcn_s_waitcnt(0x0F74);                            // vmcnt(4): the table pieces have landed (stage 0's four may stay in flight) ...
+    if constexpr (TBL2) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): nothing but the table pieces is in flight
+    else __builtin_amdgcn_s_waitcnt(0x0F74);                       // vmcnt(4): the table pieces have landed (stage 0's four may stay in flight) ...
     __builtin_amdgcn_s_barrier();                                  // ... every wave's
     asm volatile("" ::: "memory");
-    fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, ring1, lane);
+    fused_relpos<WIN, WP + 1>(st, p, qi / S, qi % S, rh, ring1, TBL2 ? ring0 : ring1 + NTJ * 4096, lane);
+    if constexpr (TBL2) {
+        __builtin_amdgcn_s_barrier();                              // every wave is done with the h table in ring0
+        asm volatile("" ::: "memory");
+        SRH_DMA_STAGE(0, ring0)
+    }
     int vb0, vb1;
     vtr_bases(lane, vb0, vb1);
 
     const float c_exp = p.scale * 1.4426950408889634f;
     constexpr int NSTAGE = NT / 2;
     static_assert(NSTAGE % 2 == 0, "the key loop is unrolled by two stages");
+    // rel_h entries (one per window row) between the two tiles of a stage / per stage: the 64 x 64 window's stage is ONE row
+    constexpr int RSTEP = WIN == 64 ? 0 : RPT, RSTAGE = WIN == 64 ? 1 : 2 * RPT;
     const float* rhp = rh + (lane & 31) * (WP + 1);
     // one hand-over per stage: this wave's four pieces have landed (vmcnt(0): nothing else is in flight), the barrier makes that
     // true for every wave's pieces and says that every wave is done reading the OTHER ring stage — which the next DMA overwrites
@@ -905,8 +923,8 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
         __builtin_amdgcn_s_barrier(); \
         asm volatile("" ::: "memory"); \
         /* rel_h of the stage's two tiles first: rh_lds is not a DMA target, so its reads must come while no DMA is in flight */ \
-        const float rh0a = rhp[((rbuf) * 2) * RPT], rh1a = RPT == 2 ? rhp[((rbuf) * 2) * RPT + 1] : 0.f; \
-        const float rh0b = rhp[((rbuf) * 2 + 1) * RPT], rh1b = RPT == 2 ? rhp[((rbuf) * 2 + 1) * RPT + 1] : 0.f; \
+        const float rh0a = rhp[(rbuf) * RSTAGE], rh1a = RPT == 2 ? rhp[(rbuf) * RSTAGE + 1] : 0.f; \
+        const float rh0b = rhp[(rbuf) * RSTAGE + RSTEP], rh1b = RPT == 2 ? rhp[(rbuf) * RSTAGE + RSTEP + 1] : 0.f; \
         asm volatile("" :: "v"(rh0a), "v"(rh1a), "v"(rh0b), "v"(rh1b) : "memory"); \
         const int snext_ = (sidx) + 1 < NSTAGE ? (sidx) + 1 : (sidx);   /* last stage re-loads itself (no branch) */ \
         SRH_DMA_STAGE(snext_, other) \
@@ -919,7 +937,7 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
     for (int sidx = 0; sidx < NSTAGE; sidx += 2) {
         SRH_STAGE(sidx, ring0, ring1, 0)
         SRH_STAGE(sidx + 1, ring1, ring0, 1)
-        rhp += 4 * RPT;
+        rhp += 2 * RSTAGE;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // the tail's re-load of the last stage must not outlive the workgroup's LDS
     store_query(st, p, tok, head, lane, true);
@@ -1048,9 +1066,9 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
 #else
     p.ablate = 0;
 #endif
-    const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32)));
+    const bool mfma_path = p.hd == HD && (p.win == 14 || (p.win == p.S && (p.S == 16 || p.S == 32 || p.S == 64)));
     if (!mfma_path && attention_hdx_supported(p)) return launch_attention_hdx(p, s);
-    if (!mfma_path) {      // other head dims / windows (ViT-H at 512 px, the 64x64 global window of 1024-pixel tiles)
+    if (!mfma_path) {      // other head dims / windows (ViT-H at 512 / 1024 px)
         if ((p.hd != 64 && p.hd != 80) || !p.table_h || !p.table_w || p.win > 64) return -2;
         const int nw = (p.S + p.win - 1) / p.win, nqb = (p.win * p.win + 255) / 256;
         const int lds = (p.win > 32 ? GEN_KC / 2 : GEN_KC) * p.hd * 6 + 256 * 2 * p.win * 4;
@@ -1074,6 +1092,7 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
         if (p.S == 32 && p.ablate == 13) hipLaunchKernelGGL((attn_global_kernel<32, 2>), dim3(grid), dim3(256), 0, s, p);        // probe builds: two workgroups / CU
         else if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
         else if (p.S == 16) hipLaunchKernelGGL((attn_global_kernel<16, 2>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.S == 64) hipLaunchKernelGGL((attn_global_kernel<64, 2>), dim3(grid), dim3(256), 0, s, p);   // 65 KiB of static LDS: two workgroups per CU
         else return -2;
     } else if (p.win == 14) {
         static OncePerDevice window_opt_in;

@@ -1,106 +1,225 @@
-// Tail of the naive map decoder and the scene-level mask fusion.
+// The naive map decoder (one fused kernel) and the scene-level mask fusion.
 //
 // Reference: model.py:286-295 (ConvTranspose2d k2 s2 x4, LayerNorm2d, exact GELU), :445-446/:490-494
 // (sigmoid, NCHW -> NHWC) and inferencer.py:79-110 (scatter-add of the two masks + coverage
 // counter, divide, x255, truncate to u8).
 //
 // A stride-2 kernel-2 transposed conv does not overlap: every input pixel owns a 2x2 output
-// block, so each layer is a per-pixel GEMM to 4*Cout columns (done by gemm.hip) and the rows of
-// the successive activations are in quad-tree order (pixel, sub1, sub2, sub3).  This file holds the
-// last layer (32 -> 2 channels, N = 8: too thin for MFMA), fused with the sigmoid and with the
-// quad-tree -> row-major NHWC scatter; it is write-bound (16 B/px logits+scores).
+// block, so each layer is a per-pixel GEMM to 4*Cout columns and the successive activations of a
+// token form a quad tree (pixel, sub1, sub2, sub3) that one wave can walk in registers.
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace srh {
 
-// ---- the last TWO layers in one kernel ---------------------------------------------------------------------
-// ConvT(64->32, k2 s2) + GELU + ConvT(32->2, k2 s2) + sigmoid + quad-tree -> NHWC scatter (model.py:292-295, :445-446).
-// The layer-by-layer path wrote the 64 -> 4 x 32 activations (67 MB per 16 tiles) for decode_out_kernel to read back; here
-// one wave keeps 16 level-2 rows in registers through both layers with the transposed MFMA chain of topo_fused.hip:
-// U^T[sub3*32 + co, row] = W5 . X^T (v_mfma_f32_16x16x32_f16, A = W5 fragments held in registers for the wave's whole
-// life, B = the rows straight from memory), bias + GELU in the C layout, and a pair of C tiles IS the B operand of the
-// last layer if its weights are packed with the k permutation 8 g + j -> 16 (j >> 2) + 4 g + (j & 3).  The 8 x 32 f32 weights
-// of the last layer enter as an fp16 hi + lo pair (two MFMAs), which keeps their f32 value to 2^-22.
-// Per lane the output tile holds one 2-pixel x 2-class float4 of one output row: exactly decode_out_kernel's stores.
-__global__ __launch_bounds__(256) void decode_tail_kernel(DecodeTailParams p) {
-    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const long ctiles = (long)p.B * p.S * p.S;                       // 16 level-2 rows each = one token's 4 x 4 block
-    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
-    f16x8 a5[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) a5[t][kb] = *reinterpret_cast<const f16x8*>(p.w5 + (size_t)(16 * t + n) * 64 + 32 * kb + 8 * g);
-    f32x4 b5[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) b5[t] = *reinterpret_cast<const f32x4*>(p.b5 + 16 * t + 4 * g);
+// ---- the whole map_decoder in one kernel ----------------------------------------------------------------------------
+// ConvT(256->128, k2 s2) + LayerNorm2d(128) + GELU + ConvT(128->64) + GELU + ConvT(64->32) + GELU + ConvT(32->2) + sigmoid + the
+// quad-tree -> NHWC scatter (model.py:286-295, :445-446).  Every stage is per-source-token independent (a stride-2 kernel-2
+// transposed conv never overlaps), so nothing but the 8 MB of neck output comes in and nothing but the masks goes out; the
+// layer-by-layer path (two GEMM launches, a LayerNorm2d pass and the two-layer tail kernel) moved 33 MB f32 + 17 MB + 33 MB of
+// intermediates through HBM for 0.84 GFLOP per tile.
+// Organisation: the transposed MFMA chain of topo_fused.hip.  Y^T[feature, token] = W . X^T with v_mfma_f32_16x16x32_f16, A = a
+// packed 16 x 32 weight fragment, B = activations; a C tile pair of one layer IS the B operand of the next if the next layer's
+// weights are packed with the k permutation 8 g + j -> 16 (j >> 2) + 4 g + (j & 3) (api.hip pack_decoder_fused).  A wave owns 32
+// tokens (two column groups that share every A fragment read) and ONE first-level sub-pixel sub1 of them: its slice of layer 0 is 128 of the
+// 512 output columns, LayerNorm2d normalises exactly those 128 channels (lane-local + two cross-lane adds), and the three later
+// layers expand it depth-first — per second-level sub-pixel 64 -> 4 x 32 channels -> 4 x (2 x 2 pixels x 2 classes) — so at most 64
+// accumulator registers are live.  A workgroup (8 waves) has sub1 = blockIdx & 3 fixed: its LDS holds that 64 KiB slice of layer 0
+// plus all of layers 3 (64 KiB) and 5 (16 KiB), loaded once; the last layer's 8 x 32 f32 weights sit in registers as an fp16 hi + lo
+// pair (two MFMAs keep their f32 value to 2^-22).  Per lane the last tile holds one 2-pixel x 2-class float4 of one output row.
+// Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles), then LDS fragment reads; HBM floor 8 MB in + 33.5 MB out.
+constexpr int DF_W0 = 65536, DF_W3 = 65536, DF_W5 = 16384, DF_NPRM = 738, DF_LDS = DF_W0 + DF_W3 + DF_W5 + 3072;
+constexpr int DF_WAVES = 8;
+
+__device__ __forceinline__ f16x8 df_pack8(const f32x4& a, const f32x4& b) {
+    f16x8 r;
+    r[0] = (f16)a[0]; r[1] = (f16)a[1]; r[2] = (f16)a[2]; r[3] = (f16)a[3];
+    r[4] = (f16)b[0]; r[5] = (f16)b[1]; r[6] = (f16)b[2]; r[7] = (f16)b[3];
+    return r;
+}
+__device__ __forceinline__ float df_sum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+
+__global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const w0 = smem;
+    char* const w3 = smem + DF_W0;
+    char* const w5 = smem + DF_W0 + DF_W3;
+    float* const prm = reinterpret_cast<float*>(smem + DF_W0 + DF_W3 + DF_W5);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int sub1 = blockIdx.x & 3;
+    {   // this workgroup's weights -> LDS, once: layer 0's slice for sub1, then layers 3 and 5 (contiguous in the packed stream)
+        const uint4* s0 = reinterpret_cast<const uint4*>(p.frags + (size_t)sub1 * DF_W0);
+        const uint4* s1 = reinterpret_cast<const uint4*>(p.frags + (size_t)4 * DF_W0);
+        uint4* d0 = reinterpret_cast<uint4*>(w0);
+        uint4* d1 = reinterpret_cast<uint4*>(w3);
+        for (int i = tid; i < DF_W0 / 16; i += DF_WAVES * 64) d0[i] = s0[i];
+        for (int i = tid; i < (DF_W3 + DF_W5) / 16; i += DF_WAVES * 64) d1[i] = s1[i];
+        for (int i = tid; i < DF_NPRM; i += DF_WAVES * 64) prm[i] = p.prm[i];
+    }
+    // the last layer's A fragment: rows n < 8 = (ky, kx, class), k = the 32 channels in the permuted order
     f16x8 a7h, a7l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ch = 16 * (j >> 2) + 4 * g + (j & 3);
-        const float v = n < 8 ? p.w7[n * 32 + ch] : 0.f;
+        const float v = n < 8 ? p.prm[480 + n * 32 + ch] : 0.f;
         a7h[j] = (f16)v;
         a7l[j] = (f16)(v - (float)a7h[j]);
     }
-    const float b7a = p.b7[0], b7b = p.b7[1];
-    const int P = p.S * 16;
-    // the next column tile's rows are fetched before the current tile's GELUs (two waves per SIMD do not hide a global load)
-    f16x8 nx0 = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, nx1 = nx0;
-    if (wave0 < ctiles) {
-        const f16* xr = p.x + ((size_t)wave0 * 16 + n) * 64 + 8 * g;
-        nx0 = *reinterpret_cast<const f16x8*>(xr); nx1 = *reinterpret_cast<const f16x8*>(xr + 32);
-    }
-    for (long ct = wave0; ct < ctiles; ct += nwaves) {
-        const f16x8 x0 = nx0, x1 = nx1;
-        if (ct + nwaves < ctiles) {
-            const f16* xr = p.x + ((size_t)(ct + nwaves) * 16 + n) * 64 + 8 * g;
-            nx0 = *reinterpret_cast<const f16x8*>(xr); nx1 = *reinterpret_cast<const f16x8*>(xr + 32);
+    const float b7a = p.prm[736], b7b = p.prm[737];
+    __syncthreads();
+#define DF_FR(base, fi) (*reinterpret_cast<const f16x8*>((base) + (fi) * 1024 + lane * 16))
+    const int S = p.S, P = S * 16;
+    const int ngroups = (p.B * S * S) >> 5;                          // 32 tokens per wave job (S * S is a multiple of 256)
+    const int wg_stride = (gridDim.x >> 2) * DF_WAVES;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int tg = (blockIdx.x >> 2) * DF_WAVES + wave; tg < ngroups; tg += wg_stride) {
+        // ---- layer 0 slice: U^T[co, token] for this sub1, K = 256 straight from memory
+        f16x8 xin[2][8];
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const f16* xr = p.emb16 + ((size_t)tg * 32 + cg * 16 + n) * 256 + 8 * g;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) xin[cg][kb] = *reinterpret_cast<const f16x8*>(xr + 32 * kb);
         }
-        f32x4 u[8];
+        f32x4 a0[8][2];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            f32x4 a = mfma16(a5[t][0], x0, f32x4{0.f, 0.f, 0.f, 0.f});
-            a = mfma16(a5[t][1], x1, a);
+        for (int rt = 0; rt < 8; ++rt) { a0[rt][0] = zero; a0[rt][1] = zero; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[t][r] = gelu_fast(a[r] + b5[t][r]);
-        }
-        // the lane's level-2 row: (tile b, token py px, sub1, sub2) = ct * 16 + n
-        long rr = ct;
-        const int s2 = n & 3, s1 = n >> 2;
-        const int px = (int)(rr % p.S); rr /= p.S;
-        const int py = (int)(rr % p.S); rr /= p.S;
-        const int b = (int)rr;
+        for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-        for (int s3 = 0; s3 < 4; ++s3) {
-            f16x8 ub;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { ub[r] = (f16)u[2 * s3][r]; ub[4 + r] = (f16)u[2 * s3 + 1][r]; }
-            f32x4 o = mfma16(a7h, ub, f32x4{0.f, 0.f, 0.f, 0.f});
-            o = mfma16(a7l, ub, o);                                   // rows 4 g + r: g = ky, r = kx * 2 + class
-            if (g < 2) {
-                const int y = (((py * 2 + (s1 >> 1)) * 2 + (s2 >> 1)) * 2 + (s3 >> 1)) * 2 + g;
-                const int xx = (((px * 2 + (s1 & 1)) * 2 + (s2 & 1)) * 2 + (s3 & 1)) * 2;
-                const size_t off = (((size_t)b * P + y) * P + xx) * 2;
-                const float4 lg = make_float4(o[0] + b7a, o[1] + b7b, o[2] + b7a, o[3] + b7b);
-                if (p.logits) *reinterpret_cast<float4*>(p.logits + off) = lg;
-                if (p.scores) {
-                    // sigmoid as rcp(1 + exp2(-x log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~25-instruction
-                    // expf + IEEE division sequence — the kernel is VALU-bound (32 GELUs + 16 sigmoids per lane and tile)
-                    auto sg = [](float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); };
-                    *reinterpret_cast<float4*>(p.scores + off) = make_float4(sg(lg.x), sg(lg.y), sg(lg.z), sg(lg.w));
-                }
+            for (int rt = 0; rt < 8; ++rt) {
+                const f16x8 a = DF_FR(w0, kb * 8 + rt);
+                a0[rt][0] = mfma16(a, xin[0][kb], a0[rt][0]);
+                a0[rt][1] = mfma16(a, xin[1][kb], a0[rt][1]);
+                if (rt == 7) __builtin_amdgcn_sched_barrier(0);      // hipcc would hoist all 64 fragment reads (256 registers) to the top
             }
+        // ---- bias + LayerNorm2d over the 128 channels of (token, sub1) + GELU -> B operands of layer 3
+        f16x8 x1[2][4];
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            float sum = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 16 * rt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a0[rt][cg][r] += b[r]; sum += a0[rt][cg][r]; }
+            }
+            const float mean = df_sum4(sum) * (1.0f / 128.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a0[rt][cg][r] -= mean; q = fmaf(a0[rt][cg][r], a0[rt][cg][r], q); }
+            const float var = df_sum4(q) * (1.0f / 128.0f);
+            if (p.nf && !(var < INFINITY) && g == 0) p.nf[p.nf_tag] = 1u;
+            const float rstd = rsqrtf(var + 1e-6f);
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(prm + 128 + 16 * rt + 4 * g);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(prm + 256 + 16 * rt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a0[rt][cg][r] = gelu_fast(a0[rt][cg][r] * rstd * ga[r] + be[r]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) x1[cg][kb] = df_pack8(a0[2 * kb][cg], a0[2 * kb + 1][cg]);
+        }
+        // the lanes' tokens and their level-1 pixel
+        int ob[2], oy[2], ox[2];
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            int tk = tg * 32 + cg * 16 + n;
+            const int px = tk % S; tk /= S;
+            const int py = tk % S; ob[cg] = tk / S;
+            oy[cg] = py * 2 + (sub1 >> 1); ox[cg] = px * 2 + (sub1 & 1);
+        }
+#pragma unroll 1
+        for (int s2 = 0; s2 < 4; ++s2) {
+            // ---- layer 3, the 64 channels of sub2: K = 128
+            f32x4 a3[4][2];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) { a3[rt][0] = zero; a3[rt][1] = zero; }
+            const char* w3s = w3 + s2 * 16384;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const f16x8 a = DF_FR(w3s, kb * 4 + rt);
+                    a3[rt][0] = mfma16(a, x1[0][kb], a3[rt][0]);
+                    a3[rt][1] = mfma16(a, x1[1][kb], a3[rt][1]);
+                    if (rt == 3 && (kb & 1)) __builtin_amdgcn_sched_barrier(0);
+                }
+            f16x8 x2[2][2];
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 384 + 16 * rt + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a3[rt][cg][r] = gelu_fast(a3[rt][cg][r] + b[r]);
+                }
+                x2[cg][0] = df_pack8(a3[0][cg], a3[1][cg]);
+                x2[cg][1] = df_pack8(a3[2][cg], a3[3][cg]);
+            }
+            // ---- layer 5: 64 -> 4 sub3 x 32 channels, K = 64
+            f32x4 a5[8][2];
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) { a5[rt][0] = zero; a5[rt][1] = zero; }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int rt = 0; rt < 8; ++rt) {
+                    const f16x8 a = DF_FR(w5, kb * 8 + rt);
+                    a5[rt][0] = mfma16(a, x2[0][kb], a5[rt][0]);
+                    a5[rt][1] = mfma16(a, x2[1][kb], a5[rt][1]);
+                    if (rt == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 448 + 16 * (rt & 1) + 4 * g);
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a5[rt][cg][r] = gelu_fast(a5[rt][cg][r] + b[r]);
+            }
+            // ---- layer 7 (32 -> 2 x 2 pixels x 2 classes) + sigmoid + scatter; rows 4 g + r: g = ky, r = kx * 2 + class
+#pragma unroll
+            for (int s3 = 0; s3 < 4; ++s3)
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    const f16x8 ub = df_pack8(a5[2 * s3][cg], a5[2 * s3 + 1][cg]);
+                    f32x4 o = mfma16(a7h, ub, zero);
+                    o = mfma16(a7l, ub, o);
+                    if (g < 2) {
+                        const int y = (((oy[cg] * 2 + (s2 >> 1)) * 2 + (s3 >> 1)) * 2) + g;
+                        const int xx = ((ox[cg] * 2 + (s2 & 1)) * 2 + (s3 & 1)) * 2;
+                        const size_t off = (((size_t)ob[cg] * P + y) * P + xx) * 2;
+                        const float4 lg = make_float4(o[0] + b7a, o[1] + b7b, o[2] + b7a, o[3] + b7b);
+                        if (p.logits) *reinterpret_cast<float4*>(p.logits + off) = lg;
+                        if (p.scores) {
+                            // sigmoid as rcp(1 + exp2(-x log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~25-instruction
+                            // expf + IEEE division sequence
+                            auto sg = [](float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); };
+                            *reinterpret_cast<float4*>(p.scores + off) = make_float4(sg(lg.x), sg(lg.y), sg(lg.z), sg(lg.w));
+                        }
+                    }
+                }
         }
     }
+#undef DF_FR
 }
 
-int launch_decode_tail(const DecodeTailParams& p, hipStream_t s) {
-    const long ctiles = (long)p.B * p.S * p.S;
-    if (ctiles <= 0) return 0;
-    const long want = (ctiles + 15) / 16;                                // >= 4 column tiles per wave when there is enough work
-    const unsigned grid = (unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want);
-    hipLaunchKernelGGL(decode_tail_kernel, dim3(grid), dim3(256), 0, s, p);
+int launch_decode_fused(const DecodeFusedParams& p, hipStream_t s) {
+    const long T = (long)p.B * p.S * p.S;
+    if (T <= 0) return 0;
+    if (T % 32 || (p.S != 16 && p.S != 32 && p.S != 64)) return -2;
+    static OncePerDevice opt_in;
+    if (!opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(decode_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS) == hipSuccess; }))
+        return -3;
+    const long ngroups = T / 32;
+    const long per_sub = (ngroups + DF_WAVES - 1) / DF_WAVES;            // workgroups per sub1 when every wave gets one job
+    const unsigned grid = 4u * (unsigned)(per_sub < 64 ? per_sub : 64);  // one workgroup per CU at most (150 KiB of LDS each)
+    hipLaunchKernelGGL(decode_fused_kernel, dim3(grid), dim3(DF_WAVES * 64), DF_LDS, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = min(row0 + r, p.M - 1);
-            const float* x = p.x + (size_t)row * p.D;
+            const float* x = p.x + (size_t)(p.x_period ? row % p.x_period : row) * p.D;
             if (p.delta16) {
                 const f16* d = p.delta16 + (size_t)row * p.D;
 #pragma unroll
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(NormParams p) {
                 float q = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { v[r][e] -= mean; q += v[r][e] * v[r][e]; }
-                const float rstd = rsqrtf(wave_sum(q) * inv_d + p.eps);
+                const float var = wave_sum(q) * inv_d;
+                if (p.nf && !(var < INFINITY) && lane == 0) p.nf[p.nf_tag] = 1u;     // Inf / NaN among the row's inputs (NormParams::nf)
+                const float rstd = rsqrtf(var + p.eps);
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     float y = v[r][e] * rstd * g[e] + be[e];

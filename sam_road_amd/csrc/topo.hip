@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     const int lane = threadIdx.x & 63;
     const long pt = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pt >= (long)p.B * p.N) return;
-    const int b = p.point_tile ? p.point_tile[pt] : (int)(pt / p.N);
+    const int b = p.point_tile ? min(max(p.point_tile[pt], 0), max(p.n_tiles, 1) - 1) : (int)(pt / p.N);   // a bad tile index must not read out of bounds
     const float px = point_coord(p.points, p.points_i64, pt * 2), py = point_coord(p.points, p.points_i64, pt * 2 + 1);
     // model.py:47 then ATen grid_sampler_unnormalize (align_corners=False)
     const float gx = (px / p.patch) * 2.0f - 1.0f, gy = (py / p.patch) * 2.0f - 1.0f;
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void pair_gather_kernel(PairGatherParams p) {
         src = reinterpret_cast<const int*>(p.pairs)[row * 2];
         tgt = reinterpret_cast<const int*>(p.pairs)[row * 2 + 1];
     }
+    src -= p.index_base; tgt -= p.index_base;
     // python-style negative index wrap, then clamp (out-of-range is an error in the reference)
     if (src < 0) src += p.N;
     if (tgt < 0) tgt += p.N;

@@ -236,11 +236,28 @@ def _launch_pass2_batches(net, emb, plan, pts_d, pairs_d, valid_d, K, lo=0):
     return out
 
 
+def _cfg_switch(v, default):
+    """One parser for the boolean switches a YAML / override may spell several ways (PASS2_RAGGED, TILE_SHARD_PIPELINE): a missing key
+    (the Config object's empty node) or None is the default; 'false' / 'no' / 'off' / '0' / '' are False; anything else bool(v)."""
+    if v is None or (not isinstance(v, (bool, int, float, str)) and not v):     # absent key: addict-style empty node
+        return default
+    if isinstance(v, str):
+        return v.strip().lower() not in ("false", "no", "off", "0", "")
+    return bool(v)
+
+
+def _poll_finite(net, device):
+    """The library's non-finite sentinel (SAMRoad.check_finite, no synchronisation): an fp16 overflow in the encoder raises here instead
+    of producing silently wrong masks.  The CPU stand-in models of the gloo tests have no such method."""
+    chk = getattr(net, "check_finite", None)
+    if chk is not None:
+        chk(device, synchronize=False)
+
+
 def _ragged_pass2(net, config):
     """Pass 2 without padding (srh_toponet_ragged: one launch for all query rows of the scene's tiles) unless the config switches it
     off (PASS2_RAGGED: False) or the model object has no such entry point (the CPU stand-in of the gloo tests)."""
-    v = config.PASS2_RAGGED
-    return (bool(v) if isinstance(v, bool) else True) and hasattr(net, "infer_toponet_ragged")
+    return _cfg_switch(config.PASS2_RAGGED, True) and hasattr(net, "infer_toponet_ragged")
 
 
 def _pack_pass2_ragged(fq, K, alloc=None):
@@ -262,6 +279,11 @@ def _pack_pass2_ragged(fq, K, alloc=None):
                                  pairs_h.ctypes.data, valid_h.ctypes.data, tile_h.ctypes.data) != 0:
         raise _lib.SrhError("srh_pass2_pack_ragged failed")
     return R, pts_h, tile_h, pairs_h, valid_h
+
+
+def _ragged_offsets(fq):
+    """Row offsets of fq's tiles counted from 0 (int64 [n_tiles + 1]): what srh_toponet_ragged chunks the scene by."""
+    return np.ascontiguousarray(np.asarray(fq.offsets, dtype=np.int64) - int(fq.offsets[0]))
 
 
 def _ragged_batches(fq, scores_flat):
@@ -397,7 +419,8 @@ def edge_votes(net, emb, graph_points, infos, lo, hi, config, device, raw=False)
         R, pts_h, tile_h, pairs_h, valid_h = _pack_pass2_ragged(fq, K)
         if R == 0:
             return empty
-        scores = net.infer_toponet_ragged(emb, *(torch.from_numpy(x[:R]).to(device) for x in (pts_h, tile_h, pairs_h, valid_h)))
+        scores = net.infer_toponet_ragged(emb, *(torch.from_numpy(x[:R]).to(device) for x in (pts_h, tile_h, pairs_h, valid_h)),
+                                          tile_offsets=_ragged_offsets(fq))
         scores = torch.where(torch.isnan(scores), -100.0, scores)
         lap("collate + H2D + launch (ragged)")
         host_scores = _ragged_batches(fq, scores.cpu().numpy())
@@ -577,6 +600,7 @@ def _infer_one_img(net, img, config, device=None):
     if rank == 0:
         kp_u8, road_u8 = net.scene_normalise(kp_c, road_c, xy_dev)
         kp_mask, road_mask = kp_u8.cpu().numpy(), road_u8.cpu().numpy()
+        _poll_finite(net, device)                      # the masks are on the host, so every LayerNorm pass of pass 1 has reported
         lap("normalise + mask D2H")
         graph_points = extract_graph_points(kp_mask, road_mask, config)
         lap("extract_graph_points")
@@ -689,7 +713,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None
     DESIGN.md §6), so it stays opt-in until an RCCL run exists; both give the same results (tests/test_distributed_cpu.py)."""
     if D.is_distributed() if tile_sharded is None else tile_sharded:
         if pipelined is None:
-            pipelined = bool(config.TILE_SHARD_PIPELINE)          # a missing key is an empty (falsy) Config
+            pipelined = _cfg_switch(config.TILE_SHARD_PIPELINE, False)
         if pipelined:
             yield from _infer_imgs_tile_sharded(net, imgs, config, device)
         else:
@@ -754,7 +778,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None
             pts_d, tile_d, pairs_d, valid_d = (lane.upload_staged(stage[n][:R]) for n in ("points", "point_tile", "pairs", "valid"))
             if prof and lane.cuda:
                 job.t[2].record()
-            sc = net.infer_toponet_ragged(job.emb, pts_d, tile_d, pairs_d, valid_d)
+            sc = net.infer_toponet_ragged(job.emb, pts_d, tile_d, pairs_d, valid_d, tile_offsets=_ragged_offsets(job.fq))
             sc = torch.where(torch.isnan(sc), -100.0, sc)
             if prof and lane.cuda:
                 job.t[3].record()
@@ -814,6 +838,7 @@ def infer_imgs(net, imgs, config, device=None, tile_sharded=None, pipelined=None
             lap("(consumer)")
             if cur.e1 is not None:
                 cur.e1.synchronize()                   # scene i's masks are on the host: the device is free for scene i+1
+                _poll_finite(net, device)
             lap("wait for pass-1 masks")
             img = next(it, None)
             nxt = launch_pass1(img, pools[(i + 1) % 2]) if img is not None else None

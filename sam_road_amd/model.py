@@ -451,11 +451,14 @@ class SAMRoad(nn.Module):
         return self._topo(image_embeddings, graph_points, pairs, valid, False)[1]
 
     @torch.no_grad()
-    def infer_toponet_ragged(self, image_embeddings, points, point_tile, pairs, valid):
+    def infer_toponet_ragged(self, image_embeddings, points, point_tile, pairs, valid, tile_offsets=None):
         """infer_toponet over the UNPADDED query rows of many tiles at once (pass 2 of infer_one_img, reference inferencer.py:179-207,
         which pads every batch to its longest tile): image_embeddings [n,256,h,w] (the NCHW view of the library's channels-last
         buffer), points f32 [R,2] tile-local (x, y), point_tile i32 [R] (index into image_embeddings), pairs i32 [R,K,2] (rows of
-        the flat list), valid u8 [R,K]  ->  scores f32 [R,K] (srh_toponet_ragged; rows as built by srh_pass2_pack_ragged)."""
+        the flat list), valid u8 [R,K]  ->  scores f32 [R,K] (srh_toponet_ragged; rows as built by srh_pass2_pack_ragged).
+        tile_offsets (host int64 [n + 1], rows of tile t = offsets[t] .. offsets[t+1], from 0 to R): the library then scores the scene in
+        chunks of whole tiles (<= 16 k rows each, same bits) so that its workspace does not grow with the scene; without them at most
+        65 536 rows per call."""
         dev = image_embeddings.device
         ctx, wh = self._weights(dev)
         emb = image_embeddings.permute(0, 2, 3, 1)
@@ -467,11 +470,30 @@ class SAMRoad(nn.Module):
         prs = pairs.to(device=dev, dtype=torch.int32).contiguous()
         vld = valid.to(device=dev, dtype=torch.uint8).contiguous()
         scores = torch.empty((R, K), dtype=torch.float32, device=dev)
+        off = None
+        if tile_offsets is not None:
+            import numpy as np
+            off = np.ascontiguousarray(tile_offsets, dtype=np.int64)
+            if off.shape != (emb.shape[0] + 1,):
+                raise ValueError(f"tile_offsets must have {emb.shape[0] + 1} entries (one per tile of image_embeddings + 1), got {off.shape}")
         if R * K > 0:
             with torch.cuda.device(dev):
-                ctx.check(ctx.lib.srh_toponet_ragged(ctx.handle, wh, emb.data_ptr(), pts.data_ptr(), pt.data_ptr(), prs.data_ptr(),
-                                                     vld.data_ptr(), R, K, scores.data_ptr(), self._stream(dev)), "srh_toponet_ragged")
+                ctx.check(ctx.lib.srh_toponet_ragged(ctx.handle, wh, emb.data_ptr(), int(emb.shape[0]), pts.data_ptr(), pt.data_ptr(),
+                                                     prs.data_ptr(), vld.data_ptr(), R, K, off.ctypes.data if off is not None else None,
+                                                     scores.data_ptr(), self._stream(dev)), "srh_toponet_ragged")
         return scores
+
+    def check_finite(self, device=None, synchronize=True):
+        """Raise SrhError if a LayerNorm pass of any earlier call on this device's context saw an Inf / NaN (an fp16 overflow in the
+        encoder: srh_ctx_check, SRH_ERR_NONFINITE) — the masks / embeddings of that call are invalid.  synchronize=True waits for the
+        current stream first; False only looks at what has already completed (the scene loop polls right after a scene's masks reached
+        the host).  The same condition is raised lazily by the next infer_* / scene_pass1 call.  The reference's own guards
+        (inferencer.py:206,219) only see TopoNet's scores."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ctx = _lib.Context.get(idx)
+        with torch.cuda.device(dev):
+            ctx.check(ctx.lib.srh_ctx_check(ctx.handle, self._stream(dev), 1 if synchronize else 0), "srh_ctx_check")
 
     # ---- scene level (pass 1 of infer_one_img: tile batcher + model + mask fusion) -------------------------
     @torch.no_grad()

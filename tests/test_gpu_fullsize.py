@@ -36,6 +36,9 @@ CITYSCALE_4X4 = dict(CITYSCALE, INFER_BATCH_SIZE=16, INFER_PATCHES_PER_EDGE=4)
 VITH_256 = dict(SAM_VERSION="vit_h", SAM_CKPT_PATH="", PATCH_SIZE=256, ENCODER_LORA=False, USE_SAM_DECODER=False,
                 INFER_BATCH_SIZE=64, SAMPLE_MARGIN=64, INFER_PATCHES_PER_EDGE=16)      # no TOPONET_VERSION key: 'normal'
 VITL_256 = dict(VITH_256, SAM_VERSION="vit_l")
+# config/toponet_vitb_1024.yaml (a live config): 64 x 64 tokens, 25 windows of 14 x 14 per tile, the 64 x 64 global window
+VITB_1024 = dict(SAM_VERSION="vit_b", SAM_CKPT_PATH="", PATCH_SIZE=1024, ENCODER_LORA=False, USE_SAM_DECODER=False,
+                 INFER_BATCH_SIZE=64, SAMPLE_MARGIN=64, INFER_PATCHES_PER_EDGE=16, NEIGHBOR_RADIUS=64, MAX_NEIGHBOR_QUERIES=16)
 
 _MEASURED = {}
 
@@ -227,6 +230,27 @@ def test_configs4_vith_vitl_full_depth_vs_oracle(name, cfg, B):
     ml_r, ms_r, tl_r, ts_r = oracle(rgb, points, pairs, valid)
     e_r = oracle._encode(rgb)
     ms, e = net.infer_masks_and_img_features(rgb.cuda())
+    check_masks_emb(name, e, e_r, ms, ms_r)
+    ts = net.infer_toponet(e, points.cuda(), pairs.cuda(), valid.cuda()).cpu()
+    v = valid.bool()
+    d = (ts[..., 0][v] - ts_r[..., 0][v]).abs().max().item()
+    _record(name + "_topo", topo_score_max_abs=d)
+    T.check(name + "_topo_score", d, T.TOPO_SCORE)
+
+
+@pytest.mark.parametrize("scale", [None, 10.0])
+def test_vitb1024_full_depth_vs_oracle(scale):
+    """toponet_vitb_1024.yaml (reference config/toponet_vitb_1024.yaml:3, model.py:197-204): 1024-px tiles, all 12 ViT-B blocks, B = 2 —
+    four of them attend globally over 64 x 64 = 4096 tokens (attn_global_kernel<64>, 110 of the tile's 938 GFLOP each).  Plain
+    0.02-std weights and the heavy-tailed ones (peaked softmax over 4096 keys), masks + embeddings + TopoNet against the oracle."""
+    oracle, net = build_pair(VITB_1024, seed=777, mutate=None if scale is None else _heavy_tails(scale))
+    B = 2
+    rgb = synth_tiles(B, 1024, seed=21)
+    points, pairs, valid = synth_queries(B, 128, 1024, seed=5)
+    ml_r, ms_r, tl_r, ts_r = oracle(rgb, points, pairs, valid)
+    e_r = oracle._encode(rgb)
+    ms, e = net.infer_masks_and_img_features(rgb.cuda())
+    name = "vitb1024_b2_12blocks" + ("" if scale is None else f"_heavy_x{int(scale)}")
     check_masks_emb(name, e, e_r, ms, ms_r)
     ts = net.infer_toponet(e, points.cuda(), pairs.cuda(), valid.cuda()).cpu()
     v = valid.bool()

@@ -285,3 +285,35 @@ def test_packed_weights_through_rccl_broadcast():
     other.import_packed(buf)
     got = other.infer_masks_and_img_features(rgb)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("which,B", [("image_encoder.blocks.0.mlp.lin2.weight", 8), ("image_encoder.blocks.1.attn.qkv.weight", 2),
+                                     ("image_encoder.blocks.1.attn.qkv.weight", 8)])
+def test_fp16_overflow_is_reported_not_returned_as_masks(which, B):
+    """ABI 8 non-finite sentinel (include/samroad_hip.h srh_ctx_check, SRH_ERR_NONFINITE; the reference's own guards,
+    inferencer.py:206,219, only see TopoNet's output): one weight scaled until an fp16 inter-kernel tensor overflows.  The call
+    itself is asynchronous and returns; the condition is raised by check_finite() and — lazily — by the next call on the context,
+    with the first stage that saw it in the message; reporting clears it and a healthy model runs again.  B = 8 takes the z192
+    GEMM path (fp16 branch outputs folded by the LayerNorm pass: lin2's output overflows there), B = 2 the generic epilogues (f32
+    residual add in the GEMM — only qkv16 / attn16 / hid16 are fp16)."""
+    from sam_road_amd import Config, SAMRoad, _lib
+    cfg = dict(CFG512, ENCODER_DEPTH=2, ENCODER_GLOBAL_ATTN_INDEXES=[1])
+    oracle, good = build_pair(cfg)
+    sd = {k: v.clone() for k, v in oracle.state_dict().items()}
+    sd[which] = sd[which] * 3.0e6
+    bad = SAMRoad(Config(cfg))
+    bad.load_state_dict(sd, strict=True)
+    bad.eval().to("cuda")
+    rgb = synth_tiles(B, 512, seed=3).cuda()
+    good.check_finite()                                      # nothing pending
+    s, e = bad.infer_masks_and_img_features(rgb)             # queued; the overflow happens on the device
+    with pytest.raises(_lib.SrhError, match="non-finite.*encoder block 1"):
+        bad.check_finite()
+    good.check_finite()                                      # reported once, then clear
+    s, e = bad.infer_masks_and_img_features(rgb)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.SrhError, match="non-finite"):   # lazily, by the next call on the context (no synchronisation inside)
+        good.infer_masks_and_img_features(rgb)
+    s, e = good.infer_masks_and_img_features(rgb)
+    good.check_finite()
+    assert torch.isfinite(e).all() and torch.isfinite(s).all()

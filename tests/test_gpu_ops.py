@@ -335,15 +335,17 @@ def ref_sam_attention(qkv, rel_h, rel_w, bias, B, S, heads, win, hd=64):
 # attention_hdx.hip, the 32x32 global window of a 512-pixel ViT-H tile the generic kernel.  Same peaked-softmax
 # inputs as hd = 64 (q, k ~ N(0, 1.5), rel-pos tables 0.3): logits reach tens, which whole-model tests with
 # 0.02-std weights never produce.
+# (64, 64, 64): the global window of 1024-px tiles (toponet_vitb_1024.yaml) — attn_global_kernel<64>: a key tile is half a window row,
+# the two rel-pos tables (127 rows) fill both ring stages; heads = 4 there so that B * heads = 8 takes the XCD-aware workgroup order.
 # (48, 14) and (64, 14): window geometries the 512-px path never produces — 3 query tiles (a wave without work), 4 (one each), 2 of
 # 64 and 36 queries (key split) — for the windowed kernel's work split.
-@pytest.mark.parametrize("S,win,hd", [(32, 14, 64), (32, 32, 64), (16, 14, 64), (16, 16, 64), (48, 14, 64), (64, 14, 64),
+@pytest.mark.parametrize("S,win,hd", [(32, 14, 64), (32, 32, 64), (16, 14, 64), (16, 16, 64), (48, 14, 64), (64, 14, 64), (64, 64, 64),
                                       (16, 14, 80), (16, 16, 80), (32, 14, 80), (32, 32, 80),
                                       # attention_hdx's workgroup slots (window, part of four query tiles): 25 slots with 3- and 2-tile edge
                                       # windows at S = 48, 41 slots at S = 64 (1024-px ViT-H tiles)
                                       (48, 14, 80), (64, 14, 80)])
 def test_sam_attention(ctx, S, win, hd):
-    B, heads = 2, 3
+    B, heads = 2, (4 if (S, win) == (64, 64) else 3)
     D = heads * hd
     g = torch.Generator().manual_seed(S * 100 + win + hd)
     qkv = (torch.randn(B * S * S, 3 * D, generator=g) * 1.5).half()

@@ -171,6 +171,25 @@ def test_pass2_ragged_rows_equal_padded_batches(pair):
     K = int(cfg.MAX_NEIGHBOR_QUERIES)
     R, p_h, t_h, q_h, v_h = inf._pack_pass2_ragged(fq, K)
     flat = net.infer_toponet_ragged(emb, *(torch.from_numpy(x[:R]).to(dev) for x in (p_h, t_h, q_h, v_h))).cpu().numpy()
+    # ABI 8: with the tiles' row offsets the library scores the scene in chunks of whole tiles (<= 16 384 rows per launch, so its
+    # workspace does not grow with the scene) — the same bits.  The scene is replicated until several chunks are needed.
+    offs0 = inf._ragged_offsets(fq)
+    np.testing.assert_array_equal(net.infer_toponet_ragged(emb, *(torch.from_numpy(x[:R]).to(dev) for x in (p_h, t_h, q_h, v_h)),
+                                                           tile_offsets=offs0).cpu().numpy(), flat)
+    rep, nt = int(np.ceil(40000 / R)), len(infos)
+    assert rep * R <= 65536
+    big = [np.concatenate([p_h[:R]] * rep), np.concatenate([t_h[:R] + i * nt for i in range(rep)]).astype(np.int32),
+           np.concatenate([q_h[:R] + i * R for i in range(rep)]).astype(np.int32), np.concatenate([v_h[:R]] * rep)]
+    big_off = np.concatenate([offs0[:-1] + i * R for i in range(rep)] + [np.array([rep * R], dtype=np.int64)])
+    emb_rep = emb.repeat(rep, 1, 1, 1)
+    one = net.infer_toponet_ragged(emb_rep, *(torch.from_numpy(x).to(dev) for x in big)).cpu().numpy()
+    chunked = net.infer_toponet_ragged(emb_rep, *(torch.from_numpy(x).to(dev) for x in big), tile_offsets=big_off).cpu().numpy()
+    vbig = big[3].astype(bool)
+    np.testing.assert_array_equal(chunked[vbig], one[vbig])
+    np.testing.assert_array_equal(chunked[:R][v_h[:R].astype(bool)], flat[v_h[:R].astype(bool)])
+    from sam_road_amd import _lib
+    with pytest.raises(_lib.SrhError):                      # no offsets: one launch, bounded
+        net.infer_toponet_ragged(emb_rep.repeat(2, 1, 1, 1), *(torch.from_numpy(np.concatenate([x, x])).to(dev) for x in big))
     plan, pp, pq, pv = inf._pack_pass2_batches(fq, 0, len(infos), int(cfg.INFER_BATCH_SIZE), K)
     pts_d, pairs_d, valid_d = (torch.from_numpy(x).to(dev) for x in (pp, pq, pv))
     off = np.asarray(fq.offsets)

@@ -121,6 +121,22 @@ def instrumented_rows(ctx, step, dev, nrep):
     return rows, instrumented_ms
 
 
+PER_RANK_KEYS = ("rank", "dominant_kernel_frac", "gemm_frac", "dominant_avg_launch_ms", "sustained_tiles_per_s", "smi_sclk_mhz_under_load")
+
+
+def gather_per_rank(entry, distributed):
+    """Every rank's own roofline figures (north_star: "rocprof-reported ... MFMA utilisation at 1/2/4/8 GPUs"): one all_gather of a small
+    dict per rank after the timed region, so that the N > 1 line carries each GPU's dominant-kernel fraction and sustained clock instead of
+    rank 0's alone.  Same code path on RCCL and on gloo (--plumbing-cpu, where the values are None)."""
+    import torch.distributed as dist
+    entry = {k: entry.get(k) for k in PER_RANK_KEYS}
+    if not distributed:
+        return [entry]
+    allr = [None] * dist.get_world_size()
+    dist.all_gather_object(allr, entry)
+    return allr
+
+
 def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b):
     """BASELINE configs[2] (`full`) and configs[4] (`vith256`) beside the headline, bounded (a few seconds each): the same warm-up /
     barrier / max-over-ranks timing as the headline's timed region, plus rank 0's all-GEMM roofline fraction from an instrumented pass."""
@@ -301,10 +317,11 @@ def plumbing_cpu(args):
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[round(v, 3) for v in a.tolist()] for a in allr]
+    per_rank_roofline = gather_per_rank({"rank": rank}, world > 1)      # the N > 1 line's per-rank block (values None: nothing is measured here)
     if rank == 0:
         print(json.dumps({"metric": "plumbing check (no measurement)", "value": None, "plumbing_only": True, "n_gpus": world,
                           "collective_ranks": int(ones.item()), "scenes": len(res), "graph_points": [int(r[0].shape[0]) for r in res],
-                          "edges": [int(r[1].shape[0]) for r in res], "per_rank": per_rank}))
+                          "edges": [int(r[1].shape[0]) for r in res], "per_rank": per_rank, "per_rank_roofline": per_rank_roofline}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -418,8 +435,8 @@ def main():
         for _ in range(160):
             step()
             n_s += 1
-        if rank == 0:
-            try:        # the queue holds ~0.7 s of work: the reading is taken under load
+        if rank == 0 or distributed:
+            try:        # the queue holds ~0.7 s of work: the reading is taken under load (every rank reads its own GPU's clock)
                 txt = subprocess.run(["rocm-smi", "--showclocks", "-d", str(local_rank)], capture_output=True, text=True, timeout=20).stdout
                 m = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", txt)
                 smi_clock = int(m.group(1)) if m else None
@@ -443,6 +460,7 @@ def main():
             sustained = {"tiles_per_s": round(B * n_s / el_s, 3), "seconds": round(el_s, 3)}
         sustained["steps_per_gpu"] = n_s
         sustained["smi_sclk_mhz_under_load"] = smi_clock
+        sustained["this_rank_tiles_per_s"] = round(B * n_s / el_s, 3)
 
     out = {
         "metric": "tiles/sec (512x512 ViT-B, SAMRoad.infer_masks_and_img_features: encoder + mask decoder)" if args.workload == "encdec"
@@ -460,10 +478,11 @@ def main():
     if sustained is not None:
         out["sustained_tiles_per_s"] = sustained["tiles_per_s"]
         out["sustained"] = sustained
-    if rank == 0:
-        out["build_id"] = _lib.build_id()           # sha256 of the sources libsamroad_hip.so was compiled from (sam_road_amd/build.py)
+    out["build_id"] = _lib.build_id()               # sha256 of the sources libsamroad_hip.so was compiled from (sam_road_amd/build.py)
 
-    if rank == 0 and not args.no_roofline:
+    mine = {"rank": rank, "sustained_tiles_per_s": sustained.get("this_rank_tiles_per_s") if sustained else None,
+            "smi_sclk_mhz_under_load": sustained.get("smi_sclk_mhz_under_load") if sustained else None}
+    if (rank == 0 or distributed) and not args.no_roofline:
         ctx = _lib.Context.get(local_rank)
         stream = torch.cuda.current_stream(dev).cuda_stream
         torch.cuda.synchronize(dev)
@@ -488,6 +507,8 @@ def main():
         # the dominant kernel by GPU time: the four big linear layers of every block (one kernel template)
         block_gemm = [r for r in gemm if r["name"] in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")]
         d_fl, d_ms, d_n, d_ach = agg(block_gemm)
+        mine.update(dominant_kernel_frac=round(d_ach / MFMA_PEAK_TFLOPS, 4), gemm_frac=round(ach / MFMA_PEAK_TFLOPS, 4),
+                    dominant_avg_launch_ms=round(d_ms / max(d_n, 1), 5))
         uses_z192 = WL["version"] == "vit_b" and B * (P // 16) ** 2 >= 8192
         # HBM bytes per GEMM launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command and workload
         # (tools/profile_gpu.sh + tools/summarize_profile.py -> profiles/<tag>_hbm_traffic[_<workload>].json).  A summary is used
@@ -529,6 +550,8 @@ def main():
                            "by_class_ms_per_step": {r["name"]: round(r["ms"] / nrep, 4) for r in rows}}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
+    if distributed:
+        out["per_rank_roofline"] = gather_per_rank(mine, True)       # every rank's figures, not rank 0's alone
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded CPU sample: the oracle (reference op sequence, eager fp32) on 2 tiles, 1 warm-up + 3 timed

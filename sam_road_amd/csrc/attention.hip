@@ -23,6 +23,18 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+// Per-phase shader-clock counters of attn_window_kernel (ablate 9 of tools/probes/attn_win_probe): empty in the product
+#ifdef SRH_TUNING
+#define WK_PHASE_BEGIN unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define WK_PHASE(k) if (p.ablate == 9) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
+#define WK_PHASE_END if (p.ablate == 9 && lane == 0) { unsigned long long* d_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.scratch) + ATTN_SCRATCH_BYTES) + ((size_t)(blockIdx.x & 255) * 8 + wave) * 8; \
+        for (int k_ = 0; k_ < 8; ++k_) atomicAdd(d_ + k_, tph[k_]); }
+#else
+#define WK_PHASE_BEGIN
+#define WK_PHASE(k)
+#define WK_PHASE_END
+#endif
+
 namespace srh {
 
 constexpr int HD = 64;  // head dim of ViT-B / ViT-L (ViT-H's 80: attention_hdx.hip, else attn_generic_kernel below)
@@ -449,29 +461,15 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S, nw = (S + WIN - 1) / WIN, D = p.heads * HD;
     // workgroups in win_item's order: the heaviest window shapes first, so that the launch's last round of workgroups is the light ones
-    int b, head, wy, wx;
-    if (p.ablate == 4) {                                                 // probe builds: the round-4 order (head, window, image)
-        int u = blockIdx.x;
-        head = u % p.heads; u /= p.heads;
-        const int widx = u % (nw * nw); u /= (nw * nw);
-        b = u; wy = widx / nw; wx = widx % nw;
-    } else {
-        const WinItem it = win_item(p, blockIdx.x, nw, p.B * p.heads);
-        b = it.b; head = it.head; wy = it.wy; wx = it.wx;
-    }
+    const WinItem it = win_item(p, blockIdx.x, nw, p.B * p.heads);
+    const int b = it.b, head = it.head, wy = it.wy, wx = it.wx;
     const int nry = min(WIN, S - wy * WIN), nrx = min(WIN, S - wx * WIN);
     const int nreal = nry * nrx;
     const int ntq = (nreal + 31) / 32;
     const int half = lane >> 5;
-    if (p.ablate == 7) return;                                           // launch floor (tuning builds only reach this)
-#ifdef SRH_TUNING      // probe builds, ablate 9: shader-clock ticks of each phase per wave (tools/probes/attn_win_probe)
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define WK_PHASE(k) if (p.ablate == 9) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
-#else
-#define WK_PHASE(k)
-#endif
+    WK_PHASE_BEGIN
     // work split (workgroup-uniform): ntq <= 2 -> the waves share query tiles and split the key tiles
-    const bool split = ntq <= 2 && p.ablate != 5;
+    const bool split = ntq <= 2;
     const int nsplit = split ? 4 / ntq : 1;
     const int part = split ? wave / ntq : 0;
     const int jt0 = split ? wave % ntq : wave;
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qpre[j][ks] = *reinterpret_cast<const f16x8*>(q + (ks * 2 + half) * 8);
     }
-    if (p.ablate != 2) {
+    {
         const int ii = i < 28 ? i : 0;
         const int rr = ii >= 14, cc = ii - 14 * rr;
         const int x = wx * WIN + cc;
@@ -552,16 +550,12 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
-            if (p.ablate != 3) window_relpos(st, tbl_lds, rx, ry, rh, inv_scale, lane);
+            window_relpos(st, tbl_lds, rx, ry, rh, inv_scale, lane);
         }
         WK_PHASE(3)                                       // 3: query setup + rel-pos
         if (!has) continue;
-        if (p.ablate != 1) window_keys(st, k_lds, v_lds, rhq, t0, t1, vb0, vb1, c_exp, lane);
+        window_keys(st, k_lds, v_lds, rhq, t0, t1, vb0, vb1, c_exp, lane);
         WK_PHASE(4)                                       // 4: key loops
-#ifdef SRH_TUNING
-        if (p.ablate == 8)                               // key loop x 4: (time - normal) / 3 = the key loops alone
-            for (int rep = 0; rep < 3; ++rep) window_keys(st, k_lds, v_lds, rhq, t0, t1, vb0, vb1, c_exp, lane);
-#endif
         if (!split) {
             store_query(st, p, tok, head, lane, valid);
             __builtin_amdgcn_wave_barrier();
@@ -597,237 +591,10 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(AttnParams p) {
             store_query(st, p, tok, head, lane, valid);
         }
     }
-#ifdef SRH_TUNING
-    if (p.ablate == 9 && lane == 0) {
-        WK_PHASE(6)                                       // 6: merge of the key-split partials + their stores
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.scratch) + ATTN_SCRATCH_BYTES) + ((size_t)(blockIdx.x & 255) * 8 + wave) * 8;
-        for (int k = 0; k < 8; ++k) atomicAdd(d + k, tph[k]);
-    }
-#endif
-#undef WK_PHASE
+    WK_PHASE(6)                                           // 6: merge of the key-split partials + their stores
+    WK_PHASE_END
 }
 
-#ifdef SRH_TUNING
-// ---------------------------------------------------------------------------------------------
-// Windowed attention, PERSISTENT form (round 5 EXPERIMENT — probe builds only, not shipped: measured slower than the per-window kernel,
-// 46.2 vs 41.5 us at B = 16, profiles/r05_attention_window.txt): one workgroup of 8 waves per CU walks a list of (window, image, head) items, heaviest
-// window shapes first, with the NEXT item's K / V rows DMA'd into the other of two LDS buffers — and its query fragments loaded into
-// registers — while the current item's rel-pos and key loops run.  Why: in attn_window_kernel every workgroup's life is load, then
-// compute; 512 of them start together, so the chip alternates between everybody loading and everybody computing (41.5 us against
-// 17.5 us of key loops + 5 of rel-pos, profiles/r04_attention_probe.txt).  Here only a CU's first item has an exposed load phase.
-//  * The LDS-DMA is issued from inline asm and every wait is an explicit counted s_waitcnt: the compiler does not know that LDS-DMA is
-//    in flight, so it adds none of the conservative vmcnt(0) fences (before LDS reads, ds_writes and loop headers) that made this
-//    overlap inexpressible with the DMA builtin.  What that leaves to this code: (RAW) an item's buffer is read only
-//    behind "s_waitcnt vmcnt(8); s_barrier" at the top of its iteration, 8 = exactly the VMEM operations a wave issues after that
-//    item's DMA: the 4 query-fragment loads of the item and the 4 output stores of the item before it (tests/test_isa_contract.py
-//    checks the emitted ISA for exactly that sequence, and for no scratch traffic); (WAR) the DMA into a buffer is issued behind the
-//    barrier every wave passes after it has finished the item that used the buffer last.
-//  * Every wave issues the SAME VMEM sequence per item, with no control flow around it: waves (and lanes) without a result store their
-//    4 x 16 bytes to a scratch row (AttnParams::scratch) instead of skipping the stores, and the prologue issues 4 scratch stores too.
-//    Otherwise the compiler's own vmcnt for the query-fragment loads has to assume the stores were skipped and waits for ALL stores
-//    of the previous item to be acknowledged at the top of every iteration.
-//  * 8 waves: a 196-query window's 7 query tiles run at once (one wave idles); windows with 3-4 / 1-2 query tiles split the KEY tiles
-//    2 / 4 ways over the waves and merge (max, sum, O) through the current buffer, as attn_window_kernel does.
-//  * The rel-pos tables are the same for every item of a launch: staged once.
-// Same arithmetic as attn_window_kernel item for item, except that 3-4-query-tile windows are key-split here (one fp16 ulp on a few
-// values, as for the 1-2-tile windows there).
-// ---------------------------------------------------------------------------------------------
-// The same stores with NO control flow around them: every lane writes its 64 output values to `o` (the caller points lanes / waves that
-// have no result at a scratch row).  The persistent windowed kernel needs every wave to issue exactly the same VMEM operations per item.
-__device__ __forceinline__ void store_query_to(const QState& st, f16* o, int lane) {
-    const int half = lane >> 5;
-    float lsum;
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(st.l), __float_as_uint(st.l), false, false);
-        lsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    const float inv = __builtin_amdgcn_rcpf(lsum);
-    f16x8 h[4];
-    pack_out(st, inv, half, h);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<f16x8*>(o + c * 16 + 8 * half) = h[c];
-}
-
-constexpr int WP_KV = 14 * 4096, WP_TBL = 2 * 4096, WP_RH = 8 * 32 * 17 * 4;
-constexpr int WP_LDS = 2 * WP_KV + WP_TBL + WP_RH;            // 140 288 B: one workgroup of 8 waves per CU
-
-__device__ __forceinline__ void dma16_asm(const void* src, unsigned lds_wave_uniform) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(lds_wave_uniform) : "memory");
-}
-
-__global__ __launch_bounds__(512, 1) void attn_window_p_kernel(AttnParams p) {
-    constexpr int WIN = 14;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* tbl_lds = smem + 2 * WP_KV;
-    float* rh_lds = reinterpret_cast<float*>(smem + 2 * WP_KV + WP_TBL);
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
-    const int S = p.S, nw = (S + WIN - 1) / WIN, D = p.heads * HD;
-    const int nbh = p.B * p.heads, n_items = nbh * nw * nw, G = gridDim.x;
-    int n = blockIdx.x;
-    if (n >= n_items) return;
-
-    // ---- DMA lane constants: waves 0..3 fill MFMA rows 8 wr .. 8 wr + 7 of the 7 K tiles, waves 4..7 of the 7 V tiles (swizzles on the
-    // source side, as attn_window_kernel); MFMA rows 28..31 of a tile get a copy of its key 0
-    const int kvsel = wave >> 2, wr = wave & 3;
-    const int i = wr * 8 + (lane >> 3), cpos = lane & 7;
-    const int ck = cpos ^ ((i >> 1) & 7), cv = cpos ^ (((i >> 1) & 1) * 4);
-    const int ii = i < 28 ? i : 0, rr = ii >= 14, cc = ii - 14 * rr;
-    const int coloff = kvsel ? 2 * D + cv * 8 : D + ck * 8;
-    const size_t tstride = (size_t)2 * S * p.ld;
-    auto issue = [&](const WinItem& it, int bsel) {
-        const int x = it.wx * WIN + cc;
-        const f16* row0 = p.qkv + (((size_t)it.b * S + it.wy * WIN + rr) * S + x) * p.ld + it.head * HD + coloff;
-        const f16* pad = p.bias_qkv + it.head * HD + coloff;
-        const unsigned dst = lds0 + bsel * WP_KV + kvsel * 7 * 4096 + wr * 1024;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const bool real = (it.wy * WIN + 2 * t + rr) < S && x < S;
-            dma16_asm(real ? row0 + t * tstride : pad, dst + t * 4096);
-        }
-    };
-    // the wave's role in an item: query tile jt, key tiles [t0, t0 + cnt) — windows with few query tiles split the keys over the waves
-    auto role = [&](const WinItem& it, int& nsplit, int& part, int& jt, bool& active, int& t0, int& cnt) {
-        nsplit = it.ntq >= 5 ? 1 : it.ntq >= 3 ? 2 : 4;
-        part = wave / it.ntq; jt = wave - part * it.ntq; active = part < nsplit;
-        t0 = 0; cnt = 7;
-        if (nsplit == 2) { t0 = part ? 4 : 0; cnt = part ? 3 : 4; }
-        else if (nsplit == 4) { t0 = 2 * part; cnt = part == 3 ? 1 : 2; }
-    };
-    auto load_q = [&](const WinItem& it, int jt, f16x8 (&q)[4]) {
-        const int qi = min(jt * 32 + (lane & 31), it.nreal - 1);
-        const size_t tokq = ((size_t)it.b * S + it.wy * WIN + qi / it.nrx) * S + it.wx * WIN + qi % it.nrx;
-        const f16* qp = p.qkv + tokq * p.ld + it.head * HD;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const f16x8*>(qp + (ks * 2 + half) * 8);
-    };
-
-    // ---- prologue: the tables (once), the first item's K / V, its query fragments
-    {
-        const int jrow = min(i, 2 * WIN - 2);                            // table rows 27..31 do not exist: their products are never used
-        dma16_asm((kvsel ? p.table_h : p.table_w) + (size_t)jrow * HD + ck * 8, lds0 + 2 * WP_KV + kvsel * 4096 + wr * 1024);
-    }
-    WinItem it = win_item(p, n, nw, nbh);
-    issue(it, 0);
-    int nsplit, part, jt, t0, cnt;
-    bool active;
-    role(it, nsplit, part, jt, active, t0, cnt);
-    f16x8 qn[4];
-    load_q(it, jt, qn);
-    // where lanes without a result store: 16 B per query slot, the two halves of a query adjacent — a scratch store instruction is 1 KiB contiguous
-    f16* const scratch_row = reinterpret_cast<f16*>(p.scratch) + wave * 1024 + (lane & 31) * 16;
-    {
-        QState z;                                          // the prologue's 4 scratch stores: the VMEM sequence of an iteration
-        z.l = 1.f;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z.o[dt][r] = 0.f;
-        store_query_to(z, scratch_row, lane);
-    }
-
-    const float c_exp = p.scale * 1.4426950408889634f;
-    const float inv_scale = 1.0f / p.scale;
-    float* rh = rh_lds + wave * 32 * 17;
-    const float* rhq = rh + (lane & 31) * 17 + 1;
-    int vb0, vb1;
-    vtr_bases(lane, vb0, vb1);
-#ifdef SRH_TUNING      // probe builds, ablate 9: shader-clock ticks of each phase, summed over the workgroup's items by wave 0 (tools/probes/attn_win_probe)
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define WP_PHASE(k) if (p.ablate == 9) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - tlast; tlast = tn_; }
-#else
-#define WP_PHASE(k)
-#endif
-    int bsel = 0;
-    for (;;) {
-        // this item's K / V (and, the first time, the tables) have landed: the 8 operations a wave issued after that DMA — the item's 4
-        // query-fragment loads and the previous item's (or the prologue's) 4 stores — may stay in flight
-        WP_PHASE(0)                                        // 0: tail of the previous iteration (stores, loop control)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        WP_PHASE(1)                                        // 1: waiting for this wave's DMA pieces
-        __syncthreads();
-        WP_PHASE(2)                                        // 2: waiting for the other waves at the barrier
-        const char* k_lds = smem + bsel * WP_KV;
-        const char* v_lds = k_lds + 7 * 4096;
-        QState st;
-        const int qi_raw = jt * 32 + (lane & 31);
-        const bool valid = active && qi_raw < it.nreal;
-        const int qi = min(qi_raw, it.nreal - 1);
-        const int ry = qi / it.nrx, rx = qi - ry * it.nrx;
-        const size_t tok = ((size_t)it.b * S + it.wy * WIN + ry) * S + it.wx * WIN + rx;
-        const int head = it.head;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st.q[ks] = qn[ks];
-        st.m = -INFINITY;
-        st.l = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st.o[dt][r] = 0.f;
-        if (active && p.ablate != 3) window_relpos(st, tbl_lds, rx, ry, rh, inv_scale, lane);
-        WP_PHASE(3)                                        // 3: query setup + rel-pos
-
-        // ---- the next item's operands: K / V into the other buffer (every wave is past the barrier above, so nobody reads it any more),
-        // its query fragments into registers.  Unconditional — the vmcnt counts above rely on it: the last item re-loads itself.
-        const int nn = n + G;
-        const bool more = nn < n_items;
-        const WinItem itn = win_item(p, more ? nn : n, nw, nbh);
-        issue(itn, bsel ^ 1);
-        int nsplit_n, part_n, jt_n, t0_n, cnt_n;
-        bool active_n;
-        role(itn, nsplit_n, part_n, jt_n, active_n, t0_n, cnt_n);
-        load_q(itn, jt_n, qn);
-        WP_PHASE(4)                                        // 4: next item's decode, DMA issue, query loads
-
-        if (active && p.ablate != 1) window_keys(st, k_lds, v_lds, rhq, t0, t0 + cnt, vb0, vb1, c_exp, lane);
-        const bool stored = active && part == 0;
-        WP_PHASE(5)                                        // 5: key loops
-        if (nsplit > 1) {
-            // merge the key-split partials: waves with part > 0 park (max, partial sum, O^T) in the current buffer (all key loops are done)
-            __syncthreads();
-            float* mb = reinterpret_cast<float*>(smem + bsel * WP_KV);
-            if (active && part > 0) {
-                float* w = mb + (size_t)(wave - it.ntq) * 34 * 64 + lane;
-                w[0] = st.m; w[64] = st.l;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) w[(2 + dt * 16 + r) * 64] = st.o[dt][r];
-            }
-            __syncthreads();
-            if (stored) {
-                for (int pp = 1; pp < nsplit; ++pp) {
-                    const float* rd = mb + (size_t)(wave + pp * it.ntq - it.ntq) * 34 * 64 + lane;
-                    const float m2 = rd[0], l2 = rd[64];
-                    const float m_new = fmaxf(st.m, m2);
-                    const float a1 = __builtin_amdgcn_exp2f((st.m - m_new) * c_exp), a2 = __builtin_amdgcn_exp2f((m2 - m_new) * c_exp);
-                    st.l = st.l * a1 + l2 * a2;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st.o[dt][r] = st.o[dt][r] * a1 + rd[(2 + dt * 16 + r) * 64] * a2;
-                    st.m = m_new;
-                }
-            }
-        }
-        WP_PHASE(6)                                        // 6: merge of the key-split partials
-        store_query_to(st, stored && valid ? p.out + tok * p.ldo + head * HD : scratch_row, lane);
-        if (!more) break;
-        n = nn; bsel ^= 1; it = itn;
-        nsplit = nsplit_n; part = part_n; jt = jt_n; active = active_n; t0 = t0_n; cnt = cnt_n;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the tail's re-issued DMA must not outlive the workgroup's LDS
-#ifdef SRH_TUNING
-    if (p.ablate == 9 && (tid & 63) == 0) {
-        WP_PHASE(7)
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.scratch) + ATTN_SCRATCH_BYTES) + ((size_t)blockIdx.x * 8 + wave) * 8;
-        for (int k = 0; k < 8; ++k) d[k] = tph[k];
-    }
-#endif
-#undef WP_PHASE
-}
-
-#endif  // SRH_TUNING
 
 // ---------------------------------------------------------------------------------------------
 // Global attention: one workgroup per (image, head, 128-query block); K rows and row-major V rows streamed through a
@@ -928,12 +695,10 @@ __global__ __launch_bounds__(256, OCC) void attn_global_kernel(AttnParams p) {
         asm volatile("" :: "v"(rh0a), "v"(rh1a), "v"(rh0b), "v"(rh1b) : "memory"); \
         const int snext_ = (sidx) + 1 < NSTAGE ? (sidx) + 1 : (sidx);   /* last stage re-loads itself (no branch) */ \
         SRH_DMA_STAGE(snext_, other) \
-        if (p.ablate != 1) { \
-            f16x8 kfA[4], kfB[4]; \
-            read_kfrag(kfA, ring, lane); \
-            read_kfrag(kfB, ring + 4096, lane); \
-            attn_tile2<WIN>(st, kfA, kfB, ring + 8192, ring + 8192 + 4096, vb0, vb1, rh0a, rh1a, rh0b, rh1b, c_exp, lane); \
-        } }
+        f16x8 kfA[4], kfB[4]; \
+        read_kfrag(kfA, ring, lane); \
+        read_kfrag(kfB, ring + 4096, lane); \
+        attn_tile2<WIN>(st, kfA, kfB, ring + 8192, ring + 8192 + 4096, vb0, vb1, rh0a, rh1a, rh0b, rh1b, c_exp, lane); }
     for (int sidx = 0; sidx < NSTAGE; sidx += 2) {
         SRH_STAGE(sidx, ring0, ring1, 0)
         SRH_STAGE(sidx + 1, ring1, ring0, 1)
@@ -1058,11 +823,14 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     }
 }
 
+#ifdef SRH_TUNING      // probe builds only (-Itools/probes): the persistent windowed experiment and the probe dispatcher
+#include "attn_tuning.inc"
+#endif
+
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
-#ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh): ablation switches change the RESULT
-    static const int env_abl = getenv("SRH_ATTN_ABL") ? atoi(getenv("SRH_ATTN_ABL")) : 0;
-    if (!p.ablate) p.ablate = env_abl;
+#ifdef SRH_TUNING      // probe builds only: kernel selection of tools/probes/attn_win_probe (attn_tuning.inc)
+    { int rc; if (attn_tuning_dispatch(p, s, &rc)) return rc; }
 #else
     p.ablate = 0;
 #endif
@@ -1085,12 +853,8 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     if (p.win == p.S) {
-#ifdef SRH_G64_PROBE   // tools/probes only: the generated-asm global kernel (tools/probes/attention_g64.hip), 9 / 10 = the HIP kernel
-        if (p.ablate >= 20 && p.ablate <= 28 && attention_g64_supported(p)) return launch_attention_g64(p, s);        // 20: the asm kernel, 21..28: its ablations
-#endif
         const int grid = p.B * p.heads * (p.S * p.S / 128);
-        if (p.S == 32 && p.ablate == 13) hipLaunchKernelGGL((attn_global_kernel<32, 2>), dim3(grid), dim3(256), 0, s, p);        // probe builds: two workgroups / CU
-        else if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
+        if (p.S == 32) hipLaunchKernelGGL((attn_global_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
         else if (p.S == 16) hipLaunchKernelGGL((attn_global_kernel<16, 2>), dim3(grid), dim3(256), 0, s, p);
         else if (p.S == 64) hipLaunchKernelGGL((attn_global_kernel<64, 2>), dim3(grid), dim3(256), 0, s, p);   // 65 KiB of static LDS: two workgroups per CU
         else return -2;
@@ -1100,18 +864,6 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
             return -3;
         const int nw = (p.S + 13) / 14;
         const int n_items = p.B * nw * nw * p.heads;
-#ifdef SRH_TUNING      // probe builds: ablate 40..49 = the persistent experiment (ablate - 40 = its own ablation), needs p.scratch
-        if (p.ablate >= 40 && p.ablate < 50 && p.S >= 14 && p.scratch) {
-            static OncePerDevice p_opt_in;
-            if (!p_opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_window_p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_LDS) == hipSuccess; }))
-                return -3;
-            int dev = 0; hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
-            p.ablate -= 40;
-            hipLaunchKernelGGL(attn_window_p_kernel, dim3(std::min(n_items, prop.multiProcessorCount)), dim3(512), WP_LDS, s, p);
-            return hipGetLastError() == hipSuccess ? 0 : -3;
-        }
-#endif
         hipLaunchKernelGGL(attn_window_kernel, dim3(n_items), dim3(256), WIN_LDS, s, p);
     } else {
         return -2;

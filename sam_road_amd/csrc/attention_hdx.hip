@@ -271,12 +271,7 @@ __global__ __launch_bounds__(256, WIN == 14 ? 3 : 1) void attn_hdx_kernel(AttnPa
     QStateX<KS, NDT> st;
     f16x8 tab[2][KS];
     const int jrow_t = min(lane & 31, 2 * WIN - 2);
-#ifdef SRH_TUNING      // tools/probes/hdx_probe: 3 return at once, 2 no staging (query phase on whatever LDS holds), 1 staging + rel-pos only
-    if (p.ablate == 3) return;
-    const bool do_stage = p.ablate != 2;
-#else
     constexpr bool do_stage = true;
-#endif
     {
         const f16* q = p.qkv + tok * p.ld + head * HD;
 #pragma unroll
@@ -332,9 +327,6 @@ __global__ __launch_bounds__(256, WIN == 14 ? 3 : 1) void attn_hdx_kernel(AttnPa
         }
     }
     __syncthreads();                                             // phase 0's keys are in LDS
-#ifdef SRH_TUNING
-    if (p.ablate == 1) return;
-#endif
     auto read_kf = [&](f16x8 (&kf)[KS], int t) {                 // t: tile index inside the phase
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -342,9 +334,6 @@ __global__ __launch_bounds__(256, WIN == 14 ? 3 : 1) void attn_hdx_kernel(AttnPa
     };
     const float* rhq = rh + (lane & 31) * RHS;
     auto key_tiles = [&](int t0, int nt) {                        // key tiles t0 .. t0 + nt - 1 of the window = tiles 0 .. nt - 1 of the phase
-#ifdef SRH_TUNING
-        if (p.ablate == 5 || (p.ablate == 6 && t0 > 0)) return;  // 5: no key loop at all, 6: phase 0's only
-#endif
         f16x8 kfa[KS];
         if constexpr (WIN == 16) {                               // one workgroup per CU: registers for two key tiles at once
             f16x8 kfb[KS];

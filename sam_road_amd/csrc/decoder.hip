@@ -29,7 +29,9 @@ namespace srh {
 // pair (two MFMAs keep their f32 value to 2^-22).  Per lane the last tile holds one 2-pixel x 2-class float4 of one output row.
 // Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles), then LDS fragment reads; HBM floor 8 MB in + 33.5 MB out.
 constexpr int DF_W0 = 65536, DF_W3 = 65536, DF_W5 = 16384, DF_NPRM = 738, DF_LDS = DF_W0 + DF_W3 + DF_W5 + 3072;
-constexpr int DF_WAVES = 8;
+// NCG column groups of 16 tokens per wave job x NW waves per workgroup: <2, 8> shares every fragment read between two column groups
+// (half the LDS traffic, 170 VGPRs: two waves per SIMD); <1, 16> has four waves per SIMD (<= 128 VGPRs) to hide the serial
+// MFMA -> bias -> GELU -> pack -> MFMA chain of a job behind other waves' phases.
 
 __device__ __forceinline__ f16x8 df_pack8(const f32x4& a, const f32x4& b) {
     f16x8 r;
@@ -39,6 +41,7 @@ __device__ __forceinline__ f16x8 df_pack8(const f32x4& a, const f32x4& b) {
 }
 __device__ __forceinline__ float df_sum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 
+template <int NCG, int DF_WAVES>
 __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const w0 = smem;
@@ -70,34 +73,37 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
     __syncthreads();
 #define DF_FR(base, fi) (*reinterpret_cast<const f16x8*>((base) + (fi) * 1024 + lane * 16))
     const int S = p.S, P = S * 16;
-    const int ngroups = (p.B * S * S) >> 5;                          // 32 tokens per wave job (S * S is a multiple of 256)
+    constexpr int JT = 16 * NCG;                                     // tokens per wave job
+    const int ngroups = (p.B * S * S) / JT;                          // (S * S is a multiple of 256)
     const int wg_stride = (gridDim.x >> 2) * DF_WAVES;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int tg = (blockIdx.x >> 2) * DF_WAVES + wave; tg < ngroups; tg += wg_stride) {
         // ---- layer 0 slice: U^T[co, token] for this sub1, K = 256 straight from memory
-        f16x8 xin[2][8];
+        f16x8 xin[NCG][8];
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-            const f16* xr = p.emb16 + ((size_t)tg * 32 + cg * 16 + n) * 256 + 8 * g;
+        for (int cg = 0; cg < NCG; ++cg) {
+            const f16* xr = p.emb16 + ((size_t)tg * JT + cg * 16 + n) * 256 + 8 * g;
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) xin[cg][kb] = *reinterpret_cast<const f16x8*>(xr + 32 * kb);
         }
-        f32x4 a0[8][2];
+        f32x4 a0[8][NCG];
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) { a0[rt][0] = zero; a0[rt][1] = zero; }
+        for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) a0[rt][cg] = zero;
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) {
                 const f16x8 a = DF_FR(w0, kb * 8 + rt);
-                a0[rt][0] = mfma16(a, xin[0][kb], a0[rt][0]);
-                a0[rt][1] = mfma16(a, xin[1][kb], a0[rt][1]);
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg) a0[rt][cg] = mfma16(a, xin[cg][kb], a0[rt][cg]);
                 if (rt == 7) __builtin_amdgcn_sched_barrier(0);      // hipcc would hoist all 64 fragment reads (256 registers) to the top
             }
         // ---- bias + LayerNorm2d over the 128 channels of (token, sub1) + GELU -> B operands of layer 3
-        f16x8 x1[2][4];
+        f16x8 x1[NCG][4];
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
+        for (int cg = 0; cg < NCG; ++cg) {
             float sum = 0.f;
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) {
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
             for (int kb = 0; kb < 4; ++kb) x1[cg][kb] = df_pack8(a0[2 * kb][cg], a0[2 * kb + 1][cg]);
         }
         // the lanes' tokens and their level-1 pixel
-        int ob[2], oy[2], ox[2];
+        int ob[NCG], oy[NCG], ox[NCG];
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-            int tk = tg * 32 + cg * 16 + n;
+        for (int cg = 0; cg < NCG; ++cg) {
+            int tk = tg * JT + cg * 16 + n;
             const int px = tk % S; tk /= S;
             const int py = tk % S; ob[cg] = tk / S;
             oy[cg] = py * 2 + (sub1 >> 1); ox[cg] = px * 2 + (sub1 & 1);
@@ -136,22 +142,24 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
 #pragma unroll 1
         for (int s2 = 0; s2 < 4; ++s2) {
             // ---- layer 3, the 64 channels of sub2: K = 128
-            f32x4 a3[4][2];
+            f32x4 a3[4][NCG];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) { a3[rt][0] = zero; a3[rt][1] = zero; }
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg) a3[rt][cg] = zero;
             const char* w3s = w3 + s2 * 16384;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     const f16x8 a = DF_FR(w3s, kb * 4 + rt);
-                    a3[rt][0] = mfma16(a, x1[0][kb], a3[rt][0]);
-                    a3[rt][1] = mfma16(a, x1[1][kb], a3[rt][1]);
+#pragma unroll
+                    for (int cg = 0; cg < NCG; ++cg) a3[rt][cg] = mfma16(a, x1[cg][kb], a3[rt][cg]);
                     if (rt == 3 && (kb & 1)) __builtin_amdgcn_sched_barrier(0);
                 }
-            f16x8 x2[2][2];
+            f16x8 x2[NCG][2];
 #pragma unroll
-            for (int cg = 0; cg < 2; ++cg) {
+            for (int cg = 0; cg < NCG; ++cg) {
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 384 + 16 * rt + 4 * g);
@@ -162,23 +170,25 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
                 x2[cg][1] = df_pack8(a3[2][cg], a3[3][cg]);
             }
             // ---- layer 5: 64 -> 4 sub3 x 32 channels, K = 64
-            f32x4 a5[8][2];
+            f32x4 a5[8][NCG];
 #pragma unroll
-            for (int rt = 0; rt < 8; ++rt) { a5[rt][0] = zero; a5[rt][1] = zero; }
+            for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg) a5[rt][cg] = zero;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int rt = 0; rt < 8; ++rt) {
                     const f16x8 a = DF_FR(w5, kb * 8 + rt);
-                    a5[rt][0] = mfma16(a, x2[0][kb], a5[rt][0]);
-                    a5[rt][1] = mfma16(a, x2[1][kb], a5[rt][1]);
+#pragma unroll
+                    for (int cg = 0; cg < NCG; ++cg) a5[rt][cg] = mfma16(a, x2[cg][kb], a5[rt][cg]);
                     if (rt == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 448 + 16 * (rt & 1) + 4 * g);
 #pragma unroll
-                for (int cg = 0; cg < 2; ++cg)
+                for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a5[rt][cg][r] = gelu_fast(a5[rt][cg][r] + b[r]);
             }
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
 #pragma unroll
             for (int s3 = 0; s3 < 4; ++s3)
 #pragma unroll
-                for (int cg = 0; cg < 2; ++cg) {
+                for (int cg = 0; cg < NCG; ++cg) {
                     const f16x8 ub = df_pack8(a5[2 * s3][cg], a5[2 * s3 + 1][cg]);
                     f32x4 o = mfma16(a7h, ub, zero);
                     o = mfma16(a7l, ub, o);
@@ -213,13 +223,14 @@ int launch_decode_fused(const DecodeFusedParams& p, hipStream_t s) {
     const long T = (long)p.B * p.S * p.S;
     if (T <= 0) return 0;
     if (T % 32 || (p.S != 16 && p.S != 32 && p.S != 64)) return -2;
+    constexpr int NCG = 1, NW = 16;
     static OncePerDevice opt_in;
-    if (!opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(decode_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS) == hipSuccess; }))
+    if (!opt_in.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(decode_fused_kernel<NCG, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS) == hipSuccess; }))
         return -3;
-    const long ngroups = T / 32;
-    const long per_sub = (ngroups + DF_WAVES - 1) / DF_WAVES;            // workgroups per sub1 when every wave gets one job
-    const unsigned grid = 4u * (unsigned)(per_sub < 64 ? per_sub : 64);  // one workgroup per CU at most (150 KiB of LDS each)
-    hipLaunchKernelGGL(decode_fused_kernel, dim3(grid), dim3(DF_WAVES * 64), DF_LDS, s, p);
+    const long ngroups = T / (16 * NCG);
+    const long per_sub = (ngroups + NW - 1) / NW;                         // workgroups per sub1 when every wave gets one job
+    const unsigned grid = 4u * (unsigned)(per_sub < 64 ? per_sub : 64);   // one workgroup per CU at most (150 KiB of LDS each)
+    hipLaunchKernelGGL((decode_fused_kernel<NCG, NW>), dim3(grid), dim3(NW * 64), DF_LDS, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

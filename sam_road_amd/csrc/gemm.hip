@@ -441,118 +441,6 @@ __device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, un
 }
 
 
-#ifdef SRH_TUNING      // a probe kernel since gemm_pp_kernel took its layers (variants 45, 47-49, 39)
-constexpr int R8_BM = 128, R8_BN = 256, R8_XT = R8_BM * BK * 2, R8_WT = R8_BN * BK * 2, R8_STAGE = R8_XT + R8_WT, R8_NST = 3;
-constexpr int R8_LDS = R8_NST * R8_STAGE;          // 147 456 B
-__global__ __launch_bounds__(512, 1) void gemm_r8_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
-    int tile_m, tile_n;
-    tile_of_block<8>((p.M + R8_BM - 1) / R8_BM, p.N / R8_BN, tile_m, tile_n);
-    const int m0 = tile_m * R8_BM, n0 = tile_n * R8_BN;
-    const int nsplit = p.splitk > 1 ? p.splitk : 1, zsplit = blockIdx.y;
-    const int kt0 = zsplit * (p.K / BK) / nsplit, nk = (zsplit + 1) * (p.K / BK) / nsplit;
-
-    // DMA pieces of a k-tile: 8 rows x 128 B each (1 KiB), swizzle on the source side.  X has 16 (wave w: pieces w, w + 8), W has 32
-    // (wave w: pieces w, w + 8, w + 16, w + 24): 6 per wave.  Per-lane 32-bit offsets against the scalar bases A + kt*128, W + kt*128.
-    const int prow = lane >> 3, pc = lane & 7;
-    unsigned xoff[2], woff[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (i * 8 + wave) * 8 + prow;
-        xoff[i] = (unsigned)((min(m0 + r, p.M - 1) * p.lda + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (i * 8 + wave) * 8 + prow;
-        woff[i] = (unsigned)(((n0 + r) * p.ldw + ((pc ^ ((r >> 1) & 7)) * 8)) * 2);
-    }
-    const char* const abase = reinterpret_cast<const char*>(p.A);
-    const char* const wbase = reinterpret_cast<const char*>(p.W);
-    const int klast = nk - 1;
-    auto dma_ktile = [&](int kt, int stage) {
-        const char* a = abase + (size_t)kt * (BK * 2);
-        const char* w = wbase + (size_t)kt * (BK * 2);
-        const unsigned d = lds0 + stage * R8_STAGE + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dma16_saddr(xoff[i], a, d + i * 8192);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma16_saddr(woff[i], w, d + R8_XT + i * 8192);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int fkey = (frow >> 1) & 7;
-    int foff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
-    const int w_row0 = (wn * 64) * 128, x_row0 = (wm * 64) * 128;
-
-    dma_ktile(min(kt0, klast), 0);
-    dma_ktile(min(kt0 + 1, klast), 1);
-    int stage = 0;
-    for (int kt = kt0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // k-tile kt has landed (this wave's pieces); k-tile kt + 1 may stay in flight
-        __syncthreads();                                     // ... every wave's pieces; and every wave is done with k-tile kt - 1's stage
-        const int nxt = stage == 0 ? R8_NST - 1 : stage - 1; // (stage + NST - 1) % NST: the stage k-tile kt - 1 used
-#ifdef SRH_TUNING      // probe builds (gemm_probe variants 47 / 48 / 49 via prio_mode): what is the k-tile made of?
-        if (p.prio_mode == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // 2: no DMA inside the loop (stale operands)
-        else
-#endif
-        dma_ktile(
-#ifdef SRH_TUNING
-            p.prio_mode == 4 ? kt0 :             // 4: DMA + barriers only, and every k-tile re-fetches k-tile 0 (an L2-resident footprint)
-#endif
-            min(kt + R8_NST - 1, klast), nxt);         // the tail re-fetches the last k-tile: the counts above stay exact
-        // (issuing the six pieces two at a time behind the first three MFMA groups instead measured the same, profiles/r05_vith_gemm_r8.txt)
-        const char* sa = smem + stage * R8_STAGE + x_row0;
-        const char* sw = smem + stage * R8_STAGE + R8_XT + w_row0;
-        f16x8 fwA[2], fxA[2], fwB[2], fxB[2];
-#ifdef SRH_TUNING
-        if (p.prio_mode >= 3) { stage = stage == R8_NST - 1 ? 0 : stage + 1; continue; }   // 3: DMA + barriers only
-#define R8_MMA(fw, fx) { if (p.prio_mode != 1) SRH_MMA2(fw, fx) else { asm volatile("" :: "v"(fw[0]), "v"(fw[1]), "v"(fx[0]), "v"(fx[1])); } }   /* 1: fragment reads, no MFMA */
-#else
-#define R8_MMA(fw, fx) SRH_MMA2(fw, fx)
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_FRAG2(fwA, fxA, 0)
-        SRH_FRAG2(fwB, fxB, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        R8_MMA(fwA, fxA)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_FRAG2(fwA, fxA, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        R8_MMA(fwB, fxB)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_FRAG2(fwB, fxB, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        R8_MMA(fwA, fxA)
-        R8_MMA(fwB, fxB)
-        __builtin_amdgcn_sched_barrier(0);
-#undef R8_MMA
-        stage = stage == R8_NST - 1 ? 0 : stage + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail's redundant fetches have landed
-    __syncthreads();                                         // every wave is done reading operand tiles: the ring becomes epilogue staging space
-    if (nsplit > 1) {  // raw f32 partial sums; bias / residual / activation are applied by splitk_reduce_kernel
-        GemmParams q = p;
-        q.bias = nullptr; q.resid = nullptr; q.pos = nullptr; q.act = 0; q.out_f16 = nullptr;
-        q.out_f32 = p.split_ws + (size_t)zsplit * p.M * p.N; q.ldc = p.N;
-        epilogue_staged<2, 0>(q, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
-        return;
-    }
-    epilogue_staged<2, 0>(p, acc, smem + wave * 16384, m0 + wm * 64, n0 + wn * 64, lane);
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // gemm_pp_kernel (round 5) — gemm_r8_kernel's tile, ring and DMA with a PING-PONG k-loop: the two waves of a SIMD (waves w and w + 4)
@@ -700,151 +588,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     else epilogue<TWF, TXF>(q, acc, m0 + wm * TXF * 32, n0 + wn * TWF * 32, lane);
 }
 
-#ifdef SRH_TUNING
-// ---------------------------------------------------------------------------------------------------
-// gemm_ppk_kernel (round 5; PROBE builds only, variant 32: measured, correct, not faster) — the ping-pong loop for 128(M) x 320(N) tiles
-// (ViT-H fc1 at M = 2048: exactly 256 tiles) with the two groups splitting K instead of the tile.  The idea: if the ping-pong kernels
-// were bound by LDS bandwidth (fragment reads + LDS-DMA writes: 176 KiB per 128 x 256 k-tile; the 256 x 160 geometry with 32 x 160 wave
-// tiles needs 244 KiB and is slower), a LARGE wave tile — 64 x 160, ten accumulator tiles, 0.7 KiB of fragments per MFMA — would lift
-// it; eight such waves would be a 256 x 320 tile, so the two waves of a SIMD work on the SAME 64 x 160 output tile and
-// alternate over K: the k dimension is walked in half k-tiles of 32; group 0 (waves 0-3, 2 x 2 wave tiles) multiplies the even ones,
-// group 1 the odd ones, each into its own accumulators; slots as in gemm_pp_kernel (a group reads the 14 fragments of its half k-tile
-// and sends seven 1-KiB pieces — 16 rows x 64 B — of its half k-tile four ahead while the other group issues 20 MFMAs).  A half
-// k-tile is 28 KiB; five ring stages (140 KiB) hold the one being read and the four in flight; a stage is written only by its own
-// group.  At the end the groups exchange partial sums through the ring and each finishes half of the 64 x 160 tile:
-// out = (even-k sum) + (odd-k sum) — a fixed order, not the ascending-k order of the other kernels.
-// RAW: a wave waits for its own pieces of its group's next half k-tile (vmcnt(7): only the seven just sent are younger) before the
-// barrier that precedes that memory slot; WAR: the stage of half k-tile h + 4 is the stage of h - 1, read by the OTHER group one slot
-// earlier, behind a barrier.
-// Result (profiles/r05_vith_gemm_pp.txt): 1.03-1.09 us per 128 x 320 k-tile = 4.8-5.1 TFLOP/s per CU in the loop — the SAME per-CU
-// rate as gemm_pp_kernel and gemm_z192 with a third less LDS traffic per FLOP (so LDS bandwidth is not what they share), and 39.7 us on
-// ViT-H fc1 against 37.1 for gemm_r320_kernel: the partial-sum exchange and the larger epilogue cost more than the loop gains.
-// ---------------------------------------------------------------------------------------------------
-constexpr int PPK_BM = 128, PPK_BN = 320, PPK_XT = PPK_BM * 64, PPK_STAGE = (PPK_BM + PPK_BN) * 64, PPK_NST = 5;
-constexpr int PPK_LDS = PPK_NST * PPK_STAGE;       // 143 360 B
-
-__global__ __launch_bounds__(512, 1) void gemm_ppk_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3;        // waves w and w + 4 share a SIMD and an output tile; the group is the parity of the half k-tile
-    const int wm = w4 & 1, wn = w4 >> 1;             // 2 (M) x 2 (N) wave tiles of 64 x 160
-    int tile_m, tile_n;
-    tile_of_block<8>((p.M + PPK_BM - 1) / PPK_BM, p.N / PPK_BN, tile_m, tile_n);
-    const int m0 = tile_m * PPK_BM, n0 = tile_n * PPK_BN;
-    const int nk = p.K / BK;                         // iterations: one half k-tile per group each
-    const int hlast = 2 * (nk - 1) + grp;            // this group's last half k-tile
-
-    // pieces of a half k-tile: 16 rows x 64 B (four lanes per row), swizzle on the source side; X has 8, W has 20; the owning group's
-    // wave w4 sends X pieces w4, w4 + 4 and W pieces w4, w4 + 4, ..., w4 + 16
-    const int prow = lane >> 2, pc = lane & 3;
-    unsigned xoff[2], woff[5];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (i * 4 + w4) * 16 + prow;
-        xoff[i] = (unsigned)((min(m0 + r, p.M - 1) * p.lda + ((pc ^ ((r >> 2) & 3)) * 8)) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int r = (i * 4 + w4) * 16 + prow;
-        woff[i] = (unsigned)(((n0 + r) * p.ldw + ((pc ^ ((r >> 2) & 3)) * 8)) * 2);
-    }
-    const char* const abase = reinterpret_cast<const char*>(p.A);
-    const char* const wbase = reinterpret_cast<const char*>(p.W);
-    auto dma_half = [&](int h, int stage) {
-        const char* a = abase + (size_t)h * 64;
-        const char* w = wbase + (size_t)h * 64;
-        const unsigned d = lds0 + stage * PPK_STAGE + w4 * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dma16_saddr(xoff[i], a, d + i * 4096);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dma16_saddr(woff[i], w, d + PPK_XT + i * 4096);
-    };
-
-    f32x16 acc[5][2];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    int foff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 64 + (((ks * 2 + fhalf) ^ ((frow >> 2) & 3)) << 4);
-    const int x_row0 = (wm * 64) * 64, w_row0 = (wn * 160) * 64;
-
-    int stage = grp;                                  // stage of half k-tile h is h % 5
-    dma_half(min(grp, hlast), stage);
-    dma_half(min(grp + 2, hlast), stage + 2);
-    wait_vmcnt<7>();
-    __syncthreads();                                  // this group's first half k-tile has landed
-    if (grp) __syncthreads();                         // group 1 sits out slot 0
-    for (int i = 0; i < nk; ++i) {
-        const int h = 2 * i + grp;
-        // ---- memory slot
-        const char* sa = smem + stage * PPK_STAGE + x_row0;
-        const char* sw = smem + stage * PPK_STAGE + PPK_XT + w_row0;
-        f16x8 fw[2][5], fx[2][2];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int t = 0; t < 5; ++t) fw[ks][t] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + t * 2048);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) fx[ks][t] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + t * 2048);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        dma_half(min(h + 4, hlast), stage == 0 ? 4 : stage - 1);      // (h + 4) % 5 = (h - 1) % 5; the tail re-fetches: the counts stay exact
-        __syncthreads();                              // (lgkmcnt(0): the fragments are in registers)
-        // ---- compute slot
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[t][j] = mfma32(fw[ks][t], fx[ks][j], acc[t][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i == nk - 1) wait_vmcnt<0>();
-        else wait_vmcnt<7>();                         // this group's next half k-tile (sent two iterations ago) has landed
-        if (!grp || i != nk - 1) __syncthreads();
-        stage = stage >= 3 ? stage - 3 : stage + 2;
-    }
-    // ---- the two groups' partial sums: through the ring (nothing is in flight, nobody reads fragments any more).  Group 0 finishes N
-    // tiles 0, 1 and the upper half of tile 4, group 1 tiles 2, 3 and the lower half of tile 4: 80 registers travel each way, as 16-byte
-    // chunks (conflict-free: lane-consecutive), 20 KiB per wave pair and direction, one direction at a time.
-    __syncthreads();
-    char* const xch = smem + w4 * (20 * 1024) + lane * 16;
-    auto put = [&](int g, const f32x16& a) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xch + (g * 4 + q) * 1024) = f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-    };
-    auto add = [&](int g, f32x16& a) {                 // a = received + a
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(xch + (g * 4 + q) * 1024);
-            a[4 * q] = t[0] + a[4 * q]; a[4 * q + 1] = t[1] + a[4 * q + 1]; a[4 * q + 2] = t[2] + a[4 * q + 2]; a[4 * q + 3] = t[3] + a[4 * q + 3];
-        }
-    };
-    if (grp) { put(0, acc[0][0]); put(1, acc[0][1]); put(2, acc[1][0]); put(3, acc[1][1]); put(4, acc[4][0]); }
-    __syncthreads();
-    if (!grp) { add(0, acc[0][0]); add(1, acc[0][1]); add(2, acc[1][0]); add(3, acc[1][1]); add(4, acc[4][0]); }
-    __syncthreads();
-    if (!grp) { put(0, acc[2][0]); put(1, acc[2][1]); put(2, acc[3][0]); put(3, acc[3][1]); put(4, acc[4][1]); }
-    __syncthreads();
-    if (grp) { add(0, acc[2][0]); add(1, acc[2][1]); add(2, acc[3][0]); add(3, acc[3][1]); add(4, acc[4][1]); }
-    __syncthreads();                                   // the exchange area becomes the staged epilogue's per-wave transposition buffers
-    f32x16 fin[2][2], last[1][1];                      // (no runtime index into acc: that would move the accumulators to scratch)
-    if (grp) { fin[0][0] = acc[2][0]; fin[0][1] = acc[2][1]; fin[1][0] = acc[3][0]; fin[1][1] = acc[3][1]; last[0][0] = acc[4][1]; }
-    else { fin[0][0] = acc[0][0]; fin[0][1] = acc[0][1]; fin[1][0] = acc[1][0]; fin[1][1] = acc[1][1]; last[0][0] = acc[4][0]; }
-    epilogue_staged<2, 0>(p, fin, smem + wave * 16384, m0 + wm * 64, n0 + wn * 160 + grp * 64, lane);
-    epilogue<1, 1>(p, last, m0 + wm * 64 + grp * 32, n0 + wn * 160 + 128, lane);
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // 128(M) x 160(N) x 64 LDS-DMA variant for the SMALL-M layers whose 128x128 tile count misses the chip's 512 workgroup slots
@@ -1265,10 +1008,6 @@ static bool use_tile160(const GemmParams& p) {
 }
 
 static bool r320_applies(const GemmParams& p) {     // ViT-H fc1-like: one round of 128 x 320 tiles where 128 x 256 tiles would need two
-#ifdef SRH_TUNING      // probe builds: A/B switch
-    static const bool on = !(getenv("SRH_GEMM_R320") && atoi(getenv("SRH_GEMM_R320")) == 0);
-    if (!on) return false;
-#endif
     if (p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % R320_BN != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p)) return false;
     const long t320 = (long)((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN);
     const long t256 = p.N % 256 == 0 ? (long)((p.M + 127) / 128) * (p.N / 256) : 1 << 30;
@@ -1281,10 +1020,6 @@ static bool r320_applies(const GemmParams& p) {     // ViT-H fc1-like: one round
 //   * the few-tile deep-K ones with split-K — ViT-H fc2: 80 tiles x 3 slices, 43.6 us with the reduce pass against 45.9 on 128 x 128 tiles.
 // ViT-H proj (80 tiles, K = 1280: slices of 6 k-tiles) stays on the 128 x 128 ring kernel (18.4 against 22.9 / 25.7 us).
 static bool pp_shape_ok(const GemmParams& p) {
-#ifdef SRH_TUNING      // probe builds: A/B switch
-    static const bool on = !(getenv("SRH_GEMM_PP") && atoi(getenv("SRH_GEMM_PP")) == 0);
-    if (!on) return false;
-#endif
     return !(p.conv_S > 0 || p.pos || p.variant != 0 || p.M >= 4096 || p.M < 128 || p.N % 256 != 0 || p.K % BK != 0 || p.K / BK < 6 || z192_preferred(p));
 }
 static bool pp_applies(const GemmParams& p) {
@@ -1328,81 +1063,8 @@ static int launch_splitk_reduce(const GemmParams& p, hipStream_t stream) {
     return launched();
 }
 
-#ifdef SRH_TUNING
-// Probe builds only (tools/probes/build_probes.sh, -DSRH_TUNING): kernel / ablation selection by number (GemmParams::variant or
-// SRH_GEMM_VARIANT).  Returns false when the number names no kernel of this file (the product dispatch then runs).  None of this exists
-// in libsamroad_hip.so.
-static bool launch_gemm_probe_variant(const GemmParams& p, hipStream_t stream, int variant, int* rc) {
-    const int grid = ((p.M + 127) / 128) * (p.N / 128);
-    const dim3 g256(((p.M + 255) / 256) * (p.N / 256));
-    const int sk = p.split_ws && p.splitk > 1 ? p.splitk : 1;
-    *rc = -2;
-    if (variant >= 50 && variant <= 62) { *rc = launch_gemm_q192(p, stream, variant - 50); return true; }      // z192's predecessor and its ablations
-    if (variant >= 70 && variant <= 70 + z192_var_count()) { *rc = launch_gemm_z192(p, stream, variant - 70); return true; }
-    switch (variant) {
-        case 1: *rc = launch_cfg<0, 2, 2, 2, 2>(p, stream); return true;                                     // register-staged 128 x 128
-        case 2: if (p.N % 256 == 0 && p.M >= 2048) { *rc = launch_cfg<0, 4, 2, 2, 4>(p, stream); return true; } return false;
-        case 4: hipLaunchKernelGGL((gemm_glds_kernel<0, 1>), dim3(grid), dim3(256), 65536 / 2, stream, p); break;      // one-stage
-        case 11: hipLaunchKernelGGL((gemm_glds_kernel<1, 2>), dim3(grid), dim3(256), 65536, stream, p); break;         // no DMA in the k-loop
-        case 12: hipLaunchKernelGGL((gemm_glds_kernel<2, 2>), dim3(grid), dim3(256), 65536, stream, p); break;         // no reads / MFMA
-        case 20: hipLaunchKernelGGL(gemm_glds256_kernel<0>, g256, dim3(512), 131072, stream, p); break;                // 256 x 256 whatever the tile count
-        case 21: hipLaunchKernelGGL(gemm_glds256_kernel<1>, g256, dim3(512), 131072, stream, p); break;
-        case 22: hipLaunchKernelGGL(gemm_glds256_kernel<2>, g256, dim3(512), 131072, stream, p); break;
-        case 30: case 31: {                        // 128 x 160 tiles without / with the caller's split-K
-            if (p.N % 160 != 0) return true;
-            GemmParams q = p;
-            q.splitk = variant == 31 ? sk : 1;
-            hipLaunchKernelGGL(gemm_glds160_kernel, dim3(((p.M + 127) / 128) * (p.N / 160), q.splitk), dim3(256), 73728, stream, q);
-            *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
-            return true;
-        }
-        case 46:                                   // the 128 x 320 kernel
-            if (p.N % R320_BN != 0) return true;
-            hipLaunchKernelGGL(gemm_r320_kernel, dim3(((p.M + R320_BM - 1) / R320_BM) * (p.N / R320_BN), 1), dim3(512), R320_LDS, stream, p);
-            *rc = launched();
-            return true;
-        case 39: case 47: case 48: case 49: {      // r8 ablations: 47 no MFMA, 48 no DMA in the loop, 49 DMA + barriers only, 39 = 49 on one k-tile
-            if (p.N % R8_BN != 0) return true;
-            GemmParams q = p;
-            q.prio_mode = variant == 39 ? 4 : variant - 46; q.splitk = 1;
-            hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), 1), dim3(512), R8_LDS, stream, q);
-            *rc = launched();
-            return true;
-        }
-        case 33: case 35: {                        // the ping-pong kernel, 128 x 256: 35 no split-K, 33 the caller's
-            if (p.N % 256 != 0) return true;
-            GemmParams q = p; q.splitk = variant == 33 ? sk : 1;
-            hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(((p.M + 127) / 128) * (p.N / 256), q.splitk), dim3(512), pp_lds_bytes<0>(), stream, q);
-            *rc = q.splitk > 1 ? launch_splitk_reduce(q, stream) : launched();
-            return true;
-        }
-        case 32:                                   // the K-parity ping-pong kernel, 128 x 320
-            if (p.N % PPK_BN != 0) return true;
-            hipLaunchKernelGGL(gemm_ppk_kernel, dim3(((p.M + PPK_BM - 1) / PPK_BM) * (p.N / PPK_BN), 1), dim3(512), PPK_LDS, stream, p);
-            *rc = launched();
-            return true;
-        case 34: {                                 // the ping-pong kernel, 256 x 160
-            if (p.N % 160 != 0) return true;
-            GemmParams q = p; q.splitk = 1;
-            hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(((p.M + 255) / 256) * (p.N / 160), 1), dim3(512), pp_lds_bytes<1>(), stream, q);
-            *rc = launched();
-            return true;
-        }
-        case 45:                                   // the 8-wave ring kernel with the caller's split-K
-            if (p.N % R8_BN != 0) return true;
-            hipLaunchKernelGGL(gemm_r8_kernel, dim3(((p.M + R8_BM - 1) / R8_BM) * (p.N / R8_BN), sk), dim3(512), R8_LDS, stream, p);
-            *rc = sk > 1 ? launch_splitk_reduce(p, stream) : launched();
-            return true;
-        case 40: case 41:                          // the ring kernel, 4 / 3 stages, with the caller's split-K
-            if (variant == 40) hipLaunchKernelGGL((gemm_ring_kernel<4>), dim3(grid, sk), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_ring_kernel<3>), dim3(grid, sk), dim3(256), 0, stream, p);
-            *rc = sk > 1 ? launch_splitk_reduce(p, stream) : launched();
-            return true;
-        default: return false;
-    }
-    *rc = launched();
-    return true;
-}
+#ifdef SRH_TUNING      // probe builds only (tools/probes/build_probes.sh, -Itools/probes): the probe kernels, their ablation switches and the by-number dispatcher
+#include "gemm_tuning.inc"
 #endif
 
 // Kernel choice by shape — the whole product dispatch:
@@ -1420,13 +1082,10 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_ring_kernel<3, 1>), dim3(((p.M + 127) / 128) * (p.N / 128)), dim3(256), 0, stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
-#ifdef SRH_TUNING
-    static const int env_variant = getenv("SRH_GEMM_VARIANT") ? atoi(getenv("SRH_GEMM_VARIANT")) : 0;
-    { int rc; if ((p.variant || env_variant) && launch_gemm_probe_variant(p, stream, p.variant ? p.variant : env_variant, &rc)) return rc; }
-    const bool have_tables = true;               // launch_gemm_z192 falls back to a probe-owned table cache
-#else
-    const bool have_tables = p.ztab != nullptr;
+#ifdef SRH_TUNING      // probe builds: kernel / ablation selection by number (tools/probes/gemm_tuning.inc)
+    { int rc; if (gemm_tuning_dispatch(p, stream, &rc)) return rc; }
 #endif
+    const bool have_tables = p.ztab != nullptr;  // gemm_z192's tile tables live in the caller's context
     if (p.a_blocked16 || p.out_blocked16)        // only gemm_z192 understands the blocked-16 layout
         return have_tables && z192_preferred(p) ? launch_gemm_z192(p, stream) : -2;
     if (have_tables && z192_preferred(p)) return launch_gemm_z192(p, stream);
@@ -1436,16 +1095,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
             const std::pair<const void*, int> k[] = {
                 {reinterpret_cast<const void*>(gemm_glds_kernel<0, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds160_kernel), 73728},
                 {reinterpret_cast<const void*>(gemm_glds256_kernel<0>), 131072},
-#ifdef SRH_TUNING
-                {reinterpret_cast<const void*>(gemm_r8_kernel), R8_LDS},
-#endif
                 {reinterpret_cast<const void*>(gemm_pp_kernel<0>), pp_lds_bytes<0>()}, {reinterpret_cast<const void*>(gemm_r320_kernel), R320_LDS},
-#ifdef SRH_TUNING
-                {reinterpret_cast<const void*>(gemm_pp_kernel<1>), pp_lds_bytes<1>()}, {reinterpret_cast<const void*>(gemm_ppk_kernel), PPK_LDS},
-                {reinterpret_cast<const void*>(gemm_glds_kernel<1, 2>), 65536}, {reinterpret_cast<const void*>(gemm_glds_kernel<2, 2>), 65536},
-                {reinterpret_cast<const void*>(gemm_glds_kernel<0, 1>), 65536}, {reinterpret_cast<const void*>(gemm_glds256_kernel<1>), 131072},
-                {reinterpret_cast<const void*>(gemm_glds256_kernel<2>), 131072},
-#endif
             };
             for (const auto& f : k)
                 if (hipFuncSetAttribute(f.first, hipFuncAttributeMaxDynamicSharedMemorySize, f.second) != hipSuccess) return false;

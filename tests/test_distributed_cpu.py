@@ -430,6 +430,11 @@ def test_bench_launch_contract_two_ranks_on_cpu():
         assert two["collective_ranks"] == 2 and two["n_gpus"] == 2 and two["plumbing_only"] and two["value"] is None
         assert lines["plain"]["graph_points"] == two["graph_points"] and lines["plain"]["edges"] == two["edges"]
         assert len(two["per_rank"]) == 2 and two["per_rank"][1][1] > 0        # rank 1 shipped canvas bytes
+        # the N > 1 line carries EVERY rank's roofline figures (bench.gather_per_rank: one all_gather after the timed region), not rank 0's alone
+        prr = two["per_rank_roofline"]
+        assert [e["rank"] for e in prr] == [0, 1]
+        assert all(set(e) == {"rank", "dominant_kernel_frac", "gemm_frac", "dominant_avg_launch_ms", "sustained_tiles_per_s",
+                              "smi_sclk_mhz_under_load"} for e in prr)
     # a launcher environment that contradicts --gpus: refused with the launch line, nothing printed as a result
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--plumbing-cpu"], capture_output=True, text=True,
                        timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)

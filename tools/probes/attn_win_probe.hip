@@ -1,8 +1,8 @@
 // Attention probe: the windowed (LDS-DMA / ds_read_b64_tr_b16 / key split) and global kernels of attention.hip timed alone at the
-// bench shape, with the ablation switches of a SRH_TUNING build (1 no key loop, 2 no K/V staging, 3 no rel-pos, 5 no key split,
-// 7 return at once, 8 key loops x 4, 13 global kernel at two workgroups / CU, 20 the asm global-attention experiment, 21..28 its ablations).  The key split changes the rounding of the edge /
-// corner windows only: outputs with and without it are compared.  (The comparison against the round-3 kernels — register staging,
-// v_perm transposition — that this probe made before they were removed is profiles/r04_attention_dma_tr.txt.)
+// bench shape, with the kernel selection of a SRH_TUNING build (tools/probes/attn_tuning.inc: 9 the per-window kernel's phase counters,
+// 13 global kernel at two workgroups / CU, 20 the asm global-attention experiment, 21..28 its ablations, 40..49 the persistent windowed
+// experiment and ITS ablations).  The in-kernel ablation switches of the product kernels (no key loop, no staging, no rel-pos, round-4
+// order: rounds 3-5) were removed in round 6; their measurements are profiles/r04_attention_*.txt and profiles/r05_attention_window.txt.
 // Build: tools/probes/build_probes.sh.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -78,8 +78,8 @@ int main(int argc, char** argv) {
     for (int c = 0; c < 3; ++c) printf("  %-32s max |persistent - per-window| = %.3e   values differing %zu of %zu\n", names[c], md[c], nd_[c], nn[c]);
     p.out = o1;
     for (int rep = 0; rep < 3; ++rep)
-        printf("  windowed:  per-window kernel, heavy-first order %6.1f us   round-4 order %6.1f   persistent %6.1f   persistent: no key loop %6.1f   no rel-pos %6.1f   |  per-window: no key loop %6.1f   no staging %6.1f   no rel-pos %6.1f\n",
-               run(p, 0, 10, st), run(p, 4, 10, st), run(p, 40, 10, st), run(p, 41, 10, st), run(p, 43, 10, st), run(p, 1, 10, st), run(p, 2, 10, st), run(p, 3, 10, st));
+        printf("  windowed:  per-window kernel %6.1f us   persistent %6.1f   persistent: no key loop %6.1f   no rel-pos %6.1f\n",
+               run(p, 0, 10, st), run(p, 40, 10, st), run(p, 41, 10, st), run(p, 43, 10, st));
     {   // phase ticks of the persistent experiment (ablate 49): per wave of every workgroup, averaged over the workgroups
         p.ablate = 49; launch_attention(p, st); CK(hipStreamSynchronize(st));
         std::vector<unsigned long long> hd(256 * 8 * 8);
@@ -127,6 +127,6 @@ int main(int argc, char** argv) {
     printf("  global asm:  S^T accumulators in AGPRs (wrong results) %6.1f us (MFMAs alone: %6.1f)   prologue + epilogue only (no key stages) %6.1f\n",
            run(g, 27, 10, st), run(g, 25, 10, st), run(g, 28, 10, st));
     for (int rep = 0; rep < 3; ++rep)
-        printf("  global:    asm %6.1f us   HIP (LDS-DMA ring, 3 workgroups / CU) %6.1f   HIP (2 / CU) %6.1f   HIP without key loop %6.1f\n", run(g, 20, 10, st), run(g, 0, 10, st), run(g, 13, 10, st), run(g, 1, 10, st));
+        printf("  global:    asm %6.1f us   HIP (LDS-DMA ring, 3 workgroups / CU) %6.1f   HIP (2 / CU) %6.1f\n", run(g, 20, 10, st), run(g, 0, 10, st), run(g, 13, 10, st));
     return 0;
 }

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Build the standalone kernel probes.  The GEMM probe links its OWN objects of the product's GEMM sources compiled with
-# -DSRH_TUNING, which enables the kernel / ablation selection by number (SRH_GEMM_VARIANT, GemmParams::variant), the q192
+# -DSRH_TUNING -Itools/probes, which pulls in tools/probes/gemm_tuning.inc / attn_tuning.inc: the probe-only kernels and the kernel / ablation
+# selection by number (SRH_GEMM_VARIANT, GemmParams::variant, SRH_ATTN_ABL), the q192
 # schedule variants and SRH_Q192_GR / SRH_Q192_PRIO — none of which exist in libsamroad_hip.so.
 set -e
 cd "$(dirname "$0")/../.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING -Itools/probes/build"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -DSRH_TUNING -Itools/probes/build -Itools/probes"
 mkdir -p tools/probes/build
 python3 tools/kgen/gemm_z192_gen.py --variants tools/probes/build   # z192_var{k}_act{0,1}.inc + z192_var_kernels.inc: the schedule variants under test
 python3 tools/kgen/attn_g64_gen.py                                  # attn_g64_body.inc / _meta.inc: the asm global attention experiment (probe only)

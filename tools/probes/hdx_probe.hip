@@ -1,5 +1,6 @@
 // attention_hdx.hip (ViT-H: head dim 80, 14 x 14 windows / the 16 x 16 global window of 256-px tiles) timed alone at the bench shape
-// (B = 8, S = 16, 16 heads), with the ablation switches of a SRH_TUNING build: 1 staging + rel-pos only, 2 no staging (query phase on whatever LDS holds), 3 return at once, 5 no key loop, 6 phase 0's key tiles only.
+// (B = 8, S = 16, 16 heads).  (Its in-kernel ablation switches — staging only, no staging, no key loop ... — were removed from the product
+// source in round 6; what they measured is profiles/r05_attention_hdx.txt.)
 // Build: tools/probes/build_probes.sh.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -52,8 +53,7 @@ int main(int argc, char** argv) {
         if (launch_attention_hdx(p, st)) { printf("launch failed\n"); return 1; }
         CK(hipStreamSynchronize(st));
         for (int r = 0; r < 2; ++r)
-            printf("hdx win %d (B = %d):  kernel %6.1f us   staging + rel-pos only %6.1f   no staging %6.1f   return at once %6.1f   no key loop %6.1f   first four key tiles only %6.1f\n", win, B,
-                   run(p, 0, st), run(p, 1, st), run(p, 2, st), run(p, 3, st), run(p, 5, st), run(p, 6, st));
+            printf("hdx win %d (B = %d):  kernel %6.1f us\n", win, B, run(p, 0, st));
     }
     return 0;
 }

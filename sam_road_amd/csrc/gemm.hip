@@ -1104,10 +1104,11 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         return -3;
 
     // 256x256 tiles halve the L2->LDS traffic per FLOP but there are only 256 CUs: use them when the tile count fills the chip evenly
-    // (<= one round, or >= 80 % occupancy of the last round).  Not for short-K layers (decoder ConvT: K = 128 / 256): those are all
-    // prologue + epilogue, and two 128x128 workgroups per CU overlap each other's store tail.
+    // (half to one round, or >= 80 % occupancy of the last round).  Not for short-K layers (decoder ConvT: K = 128 / 256): those are all
+    // prologue + epilogue, and two 128x128 workgroups per CU overlap each other's store tail.  Not for narrow layers either: the neck's
+    // 1x1 conv (N = 256, M = 16384) is 64 such tiles — a quarter of the CUs, 31 us — and one round of 128 x 128 tiles on the ring kernel.
     const long t256 = (long)((p.M + 255) / 256) * (p.N / 256);
-    const bool fits256 = t256 <= 256 || (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8;
+    const bool fits256 = (t256 >= 128 && t256 <= 256) || (t256 > 256 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.8);
     if (p.N % 256 == 0 && p.M >= 4096 && p.K > 256 && fits256) {
         hipLaunchKernelGGL(gemm_glds256_kernel<0>, dim3((unsigned)t256), dim3(512), 131072, stream, p);
         return launched();

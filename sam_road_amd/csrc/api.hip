@@ -366,7 +366,7 @@ static void pack_topo_fused(Packer& pk, srh_weights* w, int nl) {
 //   frags: L0 [sub1 4][kb 8][rt 8] (64 KiB per sub1), L3 [sub2 4][kb 4][rt 4] (64 KiB), L5 [kb 2][rt 8] (16 KiB)
 //   prm  : b0[128] | ln gamma[128] | ln beta[128] | b3[64] | b5[32] | w7[8][32] (n = (ky*2+kx)*2 + class) | b7[2]
 static void pack_decoder_fused(Packer& pk, srh_weights* w) {
-    const size_t nfrag = 256 + 64 + 16, nprm = 128 * 3 + 64 + 32 + 256 + 2;
+    const size_t nfrag = 256 + 64 + 16, nprm = 768;         // 738 parameters, padded to 3 KiB: the kernel stages them by three 1-KiB LDS-DMA pieces
     const size_t foff = pk.alloc(nfrag * 1024), poff = pk.alloc(nprm * 4);
     size_t f = 0;
     std::vector<float> wg;                                 // the layer's GEMM weight [4 * cout][cin]

@@ -28,7 +28,7 @@ namespace srh {
 // plus all of layers 3 (64 KiB) and 5 (16 KiB), loaded once; the last layer's 8 x 32 f32 weights sit in registers as an fp16 hi + lo
 // pair (two MFMAs keep their f32 value to 2^-22).  Per lane the last tile holds one 2-pixel x 2-class float4 of one output row.
 // Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles), then LDS fragment reads; HBM floor 8 MB in + 33.5 MB out.
-constexpr int DF_W0 = 65536, DF_W3 = 65536, DF_W5 = 16384, DF_NPRM = 738, DF_LDS = DF_W0 + DF_W3 + DF_W5 + 3072;
+constexpr int DF_W0 = 65536, DF_W3 = 65536, DF_W5 = 16384, DF_PRM_BYTES = 3072, DF_LDS = DF_W0 + DF_W3 + DF_W5 + DF_PRM_BYTES;   // parameters: 738 floats, packed into 3 KiB (api.hip)
 // NCG column groups of 16 tokens per wave job x NW waves per workgroup: <2, 8> shares every fragment read between two column groups
 // (half the LDS traffic, 170 VGPRs: two waves per SIMD); <1, 16> has four waves per SIMD (<= 128 VGPRs) to hide the serial
 // MFMA -> bias -> GELU -> pack -> MFMA chain of a job behind other waves' phases.
@@ -51,26 +51,33 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const int sub1 = blockIdx.x & 3;
-    {   // this workgroup's weights -> LDS, once: layer 0's slice for sub1, then layers 3 and 5 (contiguous in the packed stream)
-        const uint4* s0 = reinterpret_cast<const uint4*>(p.frags + (size_t)sub1 * DF_W0);
-        const uint4* s1 = reinterpret_cast<const uint4*>(p.frags + (size_t)4 * DF_W0);
-        uint4* d0 = reinterpret_cast<uint4*>(w0);
-        uint4* d1 = reinterpret_cast<uint4*>(w3);
-        for (int i = tid; i < DF_W0 / 16; i += DF_WAVES * 64) d0[i] = s0[i];
-        for (int i = tid; i < (DF_W3 + DF_W5) / 16; i += DF_WAVES * 64) d1[i] = s1[i];
-        for (int i = tid; i < DF_NPRM; i += DF_WAVES * 64) prm[i] = p.prm[i];
+    {   // this workgroup's weights -> LDS, once, by LDS-DMA (1 KiB pieces, lane-linear): layer 0's slice for sub1 (64 pieces), layers 3 and 5
+        // (80, contiguous in the packed stream) and the parameters (3).  (A copy loop through registers took its L2 round trips one
+        // after the other: 9 per thread.)
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        const char* s0 = p.frags + (size_t)sub1 * DF_W0 + lane * 16;
+        const char* s1 = p.frags + (size_t)4 * DF_W0 + lane * 16;
+        for (int pc = wave; pc < DF_W0 / 1024; pc += DF_WAVES)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(s0 + pc * 1024), (lds_ptr)(w0 + pc * 1024), 16, 0, 0);
+        for (int pc = wave; pc < (DF_W3 + DF_W5) / 1024; pc += DF_WAVES)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(s1 + pc * 1024), (lds_ptr)(w3 + pc * 1024), 16, 0, 0);
+        if (wave < DF_PRM_BYTES / 1024)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const char*>(p.prm) + wave * 1024 + lane * 16),
+                                             (lds_ptr)(reinterpret_cast<char*>(prm) + wave * 1024), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     // the last layer's A fragment: rows n < 8 = (ky, kx, class), k = the 32 channels in the permuted order
     f16x8 a7h, a7l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ch = 16 * (j >> 2) + 4 * g + (j & 3);
-        const float v = n < 8 ? p.prm[480 + n * 32 + ch] : 0.f;
+        const float v = n < 8 ? prm[480 + n * 32 + ch] : 0.f;
         a7h[j] = (f16)v;
         a7l[j] = (f16)(v - (float)a7h[j]);
     }
-    const float b7a = p.prm[736], b7b = p.prm[737];
-    __syncthreads();
+    const float b7a = prm[736], b7b = prm[737];
 #define DF_FR(base, fi) (*reinterpret_cast<const f16x8*>((base) + (fi) * 1024 + lane * 16))
     const int S = p.S, P = S * 16;
     constexpr int JT = 16 * NCG;                                     // tokens per wave job
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(prm + 128 + 16 * rt + 4 * g);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(prm + 256 + 16 * rt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a0[rt][cg][r] = gelu_fast(a0[rt][cg][r] * rstd * ga[r] + be[r]);
+                for (int r = 0; r < 4; ++r) a0[rt][cg][r] = gelu_fast3(a0[rt][cg][r] * rstd * ga[r] + be[r]);
             }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) x1[cg][kb] = df_pack8(a0[2 * kb][cg], a0[2 * kb + 1][cg]);
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
                 for (int rt = 0; rt < 4; ++rt) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 384 + 16 * rt + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a3[rt][cg][r] = gelu_fast(a3[rt][cg][r] + b[r]);
+                    for (int r = 0; r < 4; ++r) a3[rt][cg][r] = gelu_fast3(a3[rt][cg][r] + b[r]);
                 }
                 x2[cg][0] = df_pack8(a3[0][cg], a3[1][cg]);
                 x2[cg][1] = df_pack8(a3[2][cg], a3[3][cg]);
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
 #pragma unroll
                 for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a5[rt][cg][r] = gelu_fast(a5[rt][cg][r] + b[r]);
+                    for (int r = 0; r < 4; ++r) a5[rt][cg][r] = gelu_fast3(a5[rt][cg][r] + b[r]);
             }
             // ---- layer 7 (32 -> 2 x 2 pixels x 2 classes) + sigmoid + scatter; rows 4 g + r: g = ky, r = kx * 2 + class
 #pragma unroll

@@ -30,6 +30,10 @@ $HIPCC --offload-arch=gfx950 tools/probes/build/attn_win_probe.o tools/probes/bu
 # head-dim-80 attention (ViT-H) alone, with its ablations
 $HIPCC $FLAGS -c tools/probes/hdx_probe.hip -o tools/probes/build/hdx_probe.o
 $HIPCC --offload-arch=gfx950 tools/probes/build/hdx_probe.o tools/probes/build/attention_hdx.o -o tools/probes/hdx_probe
+# the fused map_decoder alone: batch sweep, with and without its stores
+$HIPCC $FLAGS -c sam_road_amd/csrc/decoder.hip -o tools/probes/build/decoder.o
+$HIPCC $FLAGS -c tools/probes/decoder_probe.hip -o tools/probes/build/decoder_probe.o
+$HIPCC --offload-arch=gfx950 tools/probes/build/decoder_probe.o tools/probes/build/decoder.o -o tools/probes/decoder_probe
 for p in feed_probe pipe_probe mfma_probe dma_probe feedx_probe mfma_data_probe store_probe trans_probe ln_probe; do
   [ -f tools/probes/$p.hip ] && $HIPCC --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p
 done

@@ -121,6 +121,8 @@ def instrumented_rows(ctx, step, dev, nrep):
     return rows, instrumented_ms
 
 
+SIDE_WARMUP = 20         # untimed steps in front of each side workload's timed region
+
 PER_RANK_KEYS = ("rank", "dominant_kernel_frac", "gemm_frac", "dominant_avg_launch_ms", "sustained_tiles_per_s", "smi_sclk_mhz_under_load")
 
 
@@ -152,7 +154,10 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize(dev)
-        for _ in range(5):
+        # 20 warm-up steps (~0.1 s): these blocks start right after CPU-only legs (cpu_baseline) and a torch.cuda.empty_cache(); with 5
+        # steps some runs caught a one-off ~25 ms stall (allocator refill / clock ramp from the idle GPU) inside the 40 timed steps
+        # (full: 3 191 and 3 258 tiles/s in two runs of the same build that measured 3 710-3 740 otherwise)
+        for _ in range(SIDE_WARMUP):
             step()
         sync_all()
         t0 = time.perf_counter()
@@ -167,7 +172,7 @@ def side_workloads(args, dev, rank, local_rank, world, distributed, net_b, sd_b)
         assert all(torch.isfinite(x).all() for x in o)
         tps = world * B * steps / el
         r = {"config": f"{WL['yaml']}, batch={B} {P}x{P} tiles per GPU, {WL['what']}", "tiles_per_s": round(tps, 2),
-             "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": 5, "n_gpus": world, "dtype": "f16",
+             "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": SIDE_WARMUP, "n_gpus": world, "dtype": "f16",
              "gflop_per_tile_algorithmic": WL["gflop"],
              "whole_path_mfma_frac": round(tps / world * WL["gflop"] / 1e3 / MFMA_PEAK_TFLOPS, 4)}
         if rank == 0:

@@ -839,6 +839,11 @@ static int encode_batch(srh_ctx* c, const srh_weights* w, PatchParams pp, int B,
         gq.A = A; gq.lda = lda; gq.W = W; gq.ldw = K; gq.M = T; gq.N = D; gq.K = K; gq.bias = bias; gq.a_blocked16 = a_blocked;
         gq.out_f16 = second ? c->delta16b.as<f16>() : c->delta16.as<f16>(); gq.ldc16 = D;
         if (z192_preferred(gq)) { (second ? pend_b : pend_a) = true; return gemm(c, cls, gq, s); }
+        // Small-M models (ViT-L / ViT-H at 256 px), the attention branch: proj runs unsplit on 128 x 128 ring tiles with ~9 us of fixed cost
+        // on a ~9 us loop, and its f32 read-modify-write of x sat in that exposed epilogue.  Its output goes out as fp16 instead (half the
+        // store instructions) and the LayerNorm pass that follows anyway folds it into x — the same bytes, moved into the streaming kernel
+        // (what the z192 path does for ViT-B).
+        if (!second && !pend_a && !pend_slices && (D == 1024 || D == 1280) && gemm_splitk_factor(gq) <= 1) { pend_a = true; return gemm(c, cls, gq, s); }
         GemmParams gp = gq;
         gp.out_f16 = nullptr; gp.resid = c->x.as<float>(); gp.ldr = D; gp.out_f32 = c->x.as<float>(); gp.ldc = D;
         if (const int sk = gemm_splitk_factor(gp); sk > 1 && bias && (D == 1024 || D == 1280) && !pend_slices && !pend_a && !pend_b) {

@@ -94,6 +94,7 @@ GELU_FITS = {
     3: [0.027115101429684235, 0.49156223219618944, 1.135889844701584, 1.001923220905336],
 }
 EXPOSED_V2 = True       # the product bodies' exposed (last-tile) epilogue: False = the deferred atoms back to back, True = exposed_epilogue_v2
+EXPOSED_V3 = False      # row-major bodies: the last tile leaves through LDS straight from the AGPRs (exposed_epilogue_v3), no drain / exchange
 GELU_DEG = 3            # the product bodies' degree (PRODUCT_BODIES may override per body)
 GELU_C = GELU_FITS[5]
 
@@ -763,6 +764,117 @@ class ZGen:
                 stores(j - 1)                               # ... of the previous row block: its LDS round trip is long over
         stores(3)
 
+    def exposed_epilogue_v3(self):
+        """The last tile's epilogue without the drain (sched exposed_v3; row-major output bodies).
+
+        exposed_epilogue_v2 spends most of its ~530 instructions per wave on getting the accumulators OUT: 192 v_accvgpr_read, 96 packs, 48
+        v_permlane32_swap (+ wait states), 24 ds_write, all on one wave per SIMD at ~6 ticks per instruction.  A DS instruction takes its
+        data straight from AGPRs, and after the k-loop TWO X ring slots are free (slot 2: consumed by the last k-tile; slot 0: holds the
+        phantom next tile's k-tile 0, which nobody will read; slot 1 and the W slots still receive phantom pieces).  So a wave writes a row
+        block's raw f32 accumulators to its 16 KiB of those slots (12 ds_write_b128 from a[...]: register quad 4q..4q+3 of tile (i, j) =
+        columns 32 i + 8 q + 4 fhalf .. + 3 of row lane & 31), reads them back row-contiguously (lane + 64 r -> row, 8-column segment: two
+        ds_read_b128), adds the bias (the lane's 6 x 8 bias values are the same for every row block: read once), converts and stores
+        16 bytes per lane as 192-byte row segments — ~340 instructions, no v_accvgpr_read, no cross-lane exchange.  A wave's LDS operations
+        execute in issue order, so the read-back needs no wait behind the writes and the next row block's writes may follow the current
+        read-back immediately (values double-buffered in registers)."""
+        p = self.p
+        assert not self.out_blocked and not self.sched.get("gelu_pk")
+        VAL = [V(64, 48), V(112, 48)]
+        BIA = V(160, 48)
+        EVR = [V(208 + r) for r in range(6)]                      # read-back LDS address of item lane + 64 r
+        EVG = [V(214 + r) for r in range(6)]                      # ... and its global byte offset inside the wave's 128 x 96 block
+        lane, idx, row, seg, t, u = (V(220 + k) for k in range(6))
+        VS3 = V(227)
+        ROWB = 400                                                  # staging row pitch: 96 f32 + 16 B (8 consecutive rows hit disjoint banks)
+        TB = DW                                                     # the DMA stream registers are dead after the k-loop
+        self.lg_log = ["F"] * 7                                    # the (unused) prefetch fragment reads of a next tile's first k-step
+        nt = bool(self.sched.get("store_nt"))
+        pol = self.sched.get("store_pol", "")
+        p.v_mbcnt_lane_id(lane)
+        p.s_lshl_b32(T0, WAVE, 13)
+        p.s_add_u32(T0, T0, X_BASE)                                 # the wave's 8 KiB of X slot 0 (rows 0..15); rows 16..31 sit in slot 2 = + 65536
+        p.s_mov_b32(KBL, ROWB)
+        p.v_and_b32(row, 31, lane)                                  # staging write address: row lane & 31, 16-byte half lane >> 5
+        p.v_lshrrev_b32(u, 4, row)
+        p.v_and_b32(t, 15, row)
+        p.v_mul_lo_u32(t, t, KBL)
+        p.v_lshl_add_u32(t, u, 16, t)
+        p.v_lshrrev_b32(u, 5, lane)
+        p.v_lshl_add_u32(t, u, 4, t)
+        p.v_add_u32(VS3, T0, t)
+        p.s_lshr_b32(T1, WAVE, 1)                                   # wm
+        p.s_and_b32(T2, WAVE, 1)                                    # wn
+        p.s_lshl_b32(T3, T1, 7)
+        p.s_mul_i32(T3, T3, LDC)
+        p.s_mul_i32(TB, T2, 384)                                    # bias of the wave's 96 columns: slot PB, wn * 96 floats
+        p.s_add_u32(TB, TB, PB)
+        p.s_add_u32(TB, TB, BIAS_LDS)
+        p.s_mul_i32(T2, T2, 192)
+        p.s_add_u32(T3, T3, T2)                                     # wm * 128 rows + wn * 192 B
+        p.s_mov_b32(T1, 43691)
+        for r in range(6):
+            p.v_add_u32(idx, 64 * r, lane)
+            p.v_mul_lo_u32(row, idx, T1)
+            p.v_lshrrev_b32(row, 19, row)                           # idx // 12 (43691 / 2^19; exact for idx < 2^13)
+            p.v_mul_lo_u32(seg, row, 12)
+            p.v_sub_u32(seg, idx, seg)                              # 8-column segment of the 96-column row
+            p.v_and_b32(t, 15, row)
+            p.v_mul_lo_u32(t, t, KBL)
+            p.v_lshrrev_b32(u, 4, row)
+            p.v_lshl_add_u32(t, u, 16, t)
+            p.v_lshl_add_u32(t, seg, 5, t)
+            p.v_add_u32(EVR[r], T0, t)
+            p.v_mul_lo_u32(t, row, LDC)
+            p.v_lshl_add_u32(t, seg, 4, t)
+            p.v_add_u32(EVG[r], T3, t)
+            p.v_lshlrev_b32(t, 5, seg)
+            p.v_add_u32(t, TB, t)
+            for hq in range(2):
+                p.ds_read_b128(BIA.sub(8 * r + 4 * hq, 4), t, 16 * hq)
+                self.lg_log.append("b")
+
+        def writes(j):
+            for i in range(3):
+                for q in range(4):
+                    p.ds_write_b128(VS3, ACC.sub(16 * (4 * i + j) + 4 * q, 4), 128 * i + 32 * q)
+                    self.lg_log.append("w")
+
+        def reads(j, s_):
+            for r in range(6):
+                for hq in range(2):
+                    p.ds_read_b128(VAL[s_].sub(8 * r + 4 * hq, 4), EVR[r], 16 * hq)
+                    self.lg_log.append("R%d" % j)
+
+        def arithmetic(s_):
+            for r in range(6):
+                X = VAL[s_].sub(8 * r, 8)
+                for h in range(4):
+                    p.v_pk_add_f32(X.sub(2 * h, 2), X.sub(2 * h, 2), BIA.sub(8 * r + 2 * h, 2))
+                if self.act == 1:
+                    self.gelu_inline([X[k] for k in range(8)])
+                for h in range(4):
+                    p.v_cvt_pk_f16_f32(X[h], X[2 * h], X[2 * h + 1])
+
+        def stores(j, s_):
+            if j == 0:
+                p.s_mov_b32(T2, PO)
+            else:
+                p.s_add_u32(T2, T2, LDC32)                          # next row block: 32 rows on
+            for r in range(6):
+                if not self.sched.get("no_store"):
+                    p.buffer_store_dwordx4(VAL[s_].sub(8 * r, 4), EVG[r], RS_O, T2, nt=nt, pol=pol)
+                    self.vm_log.append("S")
+
+        writes(0)
+        reads(0, 0)
+        for j in range(4):
+            if j + 1 < 4:
+                writes(j + 1)
+                reads(j + 1, (j + 1) % 2)
+            self.wait_tag("R%d" % j)
+            arithmetic(j % 2)
+            stores(j, j % 2)
+
     # ------------------------------------------------------------------------------------------ one k-tile
     def ktile(self, kk, first, epi, drain=False):
         """k-tile kk (0..11) of a 12-k-tile body.  first: the tile's first k-tile (k-step 0 starts the accumulators with C = 0).
@@ -899,6 +1011,8 @@ class ZGen:
     def exposed_epilogue(self):
         if self.sched.get("no_epi"):
             return
+        if self.sched.get("exposed_v3", EXPOSED_V3) and self.exposed_v2 and self.deferred and not self.out_blocked:
+            return self.exposed_epilogue_v3()
         if self.exposed_v2 and self.deferred:
             return self.exposed_epilogue_v2()
         for _, _, fn in self.epi_atoms():
@@ -1096,6 +1210,8 @@ VARIANTS = {
     13: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_pol="sc1")),      # epilogue stores with other cache scopes: does the
     14: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_pol="sc0 sc1")),  # end-of-kernel L2 write-back of ~25-100 MB of dirty
     15: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, store_pol="sc0 sc1", store_nt=True)),   # output lines cost launch time?
+    16: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, exposed_v3=True)),      # round 6: last tile through LDS straight from the AGPRs
+    17: dict(deferred=True, sched=dict(gelu_deg=3, exposed_v2=True, exposed_v3=False)),     # ... and its control (= the round-6 product before it)
 }
 
 PRODUCT_BODIES = {      # gemm_z192.hip includes gemm_z192_body_<name>.inc

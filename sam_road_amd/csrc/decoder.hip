@@ -20,18 +20,19 @@ namespace srh {
 // intermediates through HBM for 0.84 GFLOP per tile.
 // Organisation: the transposed MFMA chain of topo_fused.hip.  Y^T[feature, token] = W . X^T with v_mfma_f32_16x16x32_f16, A = a
 // packed 16 x 32 weight fragment, B = activations; a C tile pair of one layer IS the B operand of the next if the next layer's
-// weights are packed with the k permutation 8 g + j -> 16 (j >> 2) + 4 g + (j & 3) (api.hip pack_decoder_fused).  A wave owns 32
-// tokens (two column groups that share every A fragment read) and ONE first-level sub-pixel sub1 of them: its slice of layer 0 is 128 of the
+// weights are packed with the k permutation 8 g + j -> 16 (j >> 2) + 4 g + (j & 3) (api.hip pack_decoder_fused).  A wave job is
+// 16 * NCG tokens (NCG column groups that share every A fragment read) and ONE first-level sub-pixel sub1 of them: its slice of layer 0 is 128 of the
 // 512 output columns, LayerNorm2d normalises exactly those 128 channels (lane-local + two cross-lane adds), and the three later
 // layers expand it depth-first — per second-level sub-pixel 64 -> 4 x 32 channels -> 4 x (2 x 2 pixels x 2 classes) — so at most 64
-// accumulator registers are live.  A workgroup (8 waves) has sub1 = blockIdx & 3 fixed: its LDS holds that 64 KiB slice of layer 0
-// plus all of layers 3 (64 KiB) and 5 (16 KiB), loaded once; the last layer's 8 x 32 f32 weights sit in registers as an fp16 hi + lo
+// accumulator registers per column group are live.  A workgroup (NW waves) has sub1 = blockIdx & 3 fixed: its LDS holds that 64 KiB slice of
+// layer 0 plus all of layers 3 (64 KiB) and 5 (16 KiB), staged once by LDS-DMA; the last layer's 8 x 32 f32 weights sit in registers as an fp16 hi + lo
 // pair (two MFMAs keep their f32 value to 2^-22).  Per lane the last tile holds one 2-pixel x 2-class float4 of one output row.
-// Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles), then LDS fragment reads; HBM floor 8 MB in + 33.5 MB out.
+// GELU = gelu_fast3 (degree-3 exponent polynomial, common.hpp).  Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles) behind a serial
+// per-wave chain; HBM floor 8 MB in + 33.5 MB out.  Measured (profiles/r06_decoder_probe.txt): 36.6 us alone at B = 16, ~42 in the model.
 constexpr int DF_W0 = 65536, DF_W3 = 65536, DF_W5 = 16384, DF_PRM_BYTES = 3072, DF_LDS = DF_W0 + DF_W3 + DF_W5 + DF_PRM_BYTES;   // parameters: 738 floats, packed into 3 KiB (api.hip)
 // NCG column groups of 16 tokens per wave job x NW waves per workgroup: <2, 8> shares every fragment read between two column groups
-// (half the LDS traffic, 170 VGPRs: two waves per SIMD); <1, 16> has four waves per SIMD (<= 128 VGPRs) to hide the serial
-// MFMA -> bias -> GELU -> pack -> MFMA chain of a job behind other waves' phases.
+// (half the LDS traffic, 170 VGPRs: two waves per SIMD; measured 52 us in the model); <1, 16> — the one launched — has four waves per
+// SIMD (104 VGPRs) to hide the serial MFMA -> bias -> GELU -> pack -> MFMA chain of a job behind other waves' phases (47 -> ~42 us).
 
 __device__ __forceinline__ f16x8 df_pack8(const f32x4& a, const f32x4& b) {
     f16x8 r;

@@ -1,17 +1,23 @@
-// f16 x f16 -> f32 MFMA GEMM with fused epilogues for the SAM ViT encoder / decoder / TopoNet
-// linear layers:  OUT[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual | + pos-embed).
+// f16 x f16 -> f32 MFMA GEMMs with fused epilogues for the linear layers z192 (gemm_z192.hip) does not take:
+//     OUT[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual | + pos-embed), fp32 and / or fp16 out.
 //
-// Replaces the ATen call sites K2/K4/K7/K8/K9/K10/K13 of SURVEY.md §2.1 (nn.Linear / 1x1 and
-// 3x3 Conv2d / ConvTranspose2d-as-GEMM in the un-vendored SAM fork and reference model.py:283-295).
+// Replaces the ATen call sites K2 / K4 / K7 / K8 / K9 / K13 of SURVEY.md §2.1 (nn.Linear, the neck's 1x1 and 3x3 Conv2d, the TopoNet
+// projections; reference model.py:245-258 through the SAM fork, :283-285, :88-117) where no generated body applies: the patch embedding
+// of ViT-L / H, every block GEMM of the small-M models (ViT-L / ViT-H at 256 px), the neck, feature_proj, the SAM-decoder branch.
 //
-// Design (gfx950): 256x256x64 block tile (512 threads = 8 waves as 4(N) x 2(M), each wave 64x128 via
-// 2x4 v_mfma_f32_32x32x16_f16 tiles = 128 accumulator registers, 128 KiB LDS, one workgroup per CU)
-// for the large layers; a 128x128x64 / 4-wave variant for thin problems (N % 256 != 0).  The MFMA is issued
-// "transposed" (A operand = weight rows, B operand = activation rows) so that every lane ends up
-// with 4 CONSECUTIVE output columns of one output row: the epilogue then does 16-byte bias /
-// residual loads and 8/16-byte stores instead of 2-byte scatters.  Operands are staged
-// global -> registers -> LDS (double buffered, loads of tile k+1 issued before the MFMAs of
-// tile k) with a 16-byte-chunk XOR swizzle so the ds_read_b128 fragment reads are conflict-free.
+// Kernels (all LDS-DMA fed unless noted; launch_gemm at the end of the file is the whole dispatch):
+//   gemm_glds256_kernel   256 x 256 tiles, 8 waves                      big layers without a z192 body, half a round of the chip or more
+//   gemm_glds_kernel      128 x 128 tiles, two stages, 2 workgroups/CU   everything small; deterministic split-K (+ splitk_reduce_kernel)
+//   gemm_ring_kernel      128 x 128 tiles, three-stage ring              <= 256 tiles with K >= 768 (ViT-H proj, the neck's 1x1); <3, 1>: the
+//                                                                        implicit 3 x 3 conv with tap-following A pieces (the neck)
+//   gemm_pp_kernel        128 x 256 tiles, 8 waves, ping-pong k-loop     small-M layers in one round (ViT-H qkv) and fc2's split-K slices
+//   gemm_r320_kernel      128 x 320 tiles, 8 waves                       ViT-H fc1
+//   gemm_glds160_kernel   128 x 160 tiles                                small-M layers whose 128 x 128 tile count misses one round
+// The MFMA is issued "transposed" (A operand = weight rows, B operand = activation rows) so that every lane ends up with 4 CONSECUTIVE
+// output columns of one output row: the epilogue does 16-byte bias / residual loads and 8 / 16-byte stores.  LDS images carry a
+// 16-byte-chunk XOR swizzle (applied on the SOURCE side of an LDS-DMA piece) so the ds_read_b128 fragment reads are conflict-free.
+// Probe builds (-DSRH_TUNING -Itools/probes) add the probe-only kernels (the register-staged round-1 kernels among them) and the
+// by-number dispatcher of tools/probes/gemm_tuning.inc.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
@@ -21,24 +27,6 @@ namespace srh {
 
 constexpr int BK = 64;
 
-// Source row for the activation operand.  AMODE 0: plain row m.  AMODE 1: implicit 3x3 conv over
-// an [B,S,S,C] channels-last grid (zero padding 1): k-tile kt addresses tap = (kt*BK)/C.
-template <int AMODE>
-__device__ __forceinline__ const f16* a_src(const GemmParams& p, int m, int kt, bool& zero) {
-    zero = false;
-    if (AMODE == 0) {
-        return p.A + (size_t)m * p.lda + kt * BK;
-    } else {
-        const int S = p.conv_S, C = p.conv_C;
-        const int k0 = kt * BK;
-        const int tap = k0 / C, c0 = k0 - tap * C;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int x = m % S, y = (m / S) % S;
-        const int yy = y + dy, xx = x + dx;
-        if (yy < 0 || yy >= S || xx < 0 || xx >= S) { zero = true; return p.A; }
-        return p.A + (size_t)(m + dy * S + dx) * p.lda + c0;
-    }
-}
 
 // Epilogue shared by the GEMM kernels: lane holds, per (i,j,q), 4 consecutive columns n..n+3 of row m.
 // fp16 output without an f32 output: the register quads q = 2 k and 2 k + 1 of a row are exchanged between the two half-waves with one
@@ -880,122 +868,6 @@ void gemm_glds256_kernel(GemmParams p) {
     epilogue_staged<4, 0>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
     __builtin_amdgcn_wave_barrier();
     epilogue_staged<4, 2>(p, acc, smem + wave * 16384, m0 + wm * 128 + 64, n0 + wn * 64, lane);
-}
-
-// Tile configuration: WN x WM waves, each wave TN x TM MFMA tiles of 32x32 (N = weight rows, M = activation rows)
-//   small: 2x2 waves, 2x2 tiles -> 128x128, 256 threads, 64 KiB LDS, 2 workgroups / CU
-//   big:   4x2 waves, 2x4 tiles -> 256(N) x 256(M), 512 threads, 128 KiB LDS, 1 workgroup / CU
-template <int AMODE, int WN, int WM, int TN, int TM>
-__global__ __launch_bounds__(WN * WM * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_kernel(GemmParams p) {
-    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, THREADS = WN * WM * 64;
-    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
-    constexpr int RSTRIDE = THREADS / 8;                 // rows between a thread's staged chunks
-    constexpr int NA = BM / RSTRIDE, NW = BN / RSTRIDE;  // chunks per thread per operand (4)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave / WM, wm = wave % WM;
-    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-    int tile_m, tile_n;
-    tile_of_block<(BM == 128 ? 8 : 4)>(tiles_m, tiles_n, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.K / BK;
-
-    // staging: thread owns 16-byte chunk `cch` of rows srow + RSTRIDE*i (i < 4) of both operands.  Named
-    // registers, not arrays: hipcc keeps `uint4 r[4]` staging arrays in scratch memory here.
-    static_assert(NA == 4 && NW == 4, "staging code assumes 4 chunks per thread per operand");
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-    const int srow = tid >> 3, cch = tid & 7;
-    const int am0 = min(m0 + srow, p.M - 1), am1 = min(m0 + srow + RSTRIDE, p.M - 1);
-    const int am2 = min(m0 + srow + 2 * RSTRIDE, p.M - 1), am3 = min(m0 + srow + 3 * RSTRIDE, p.M - 1);
-    const f16* wbase = p.W + (size_t)(n0 + srow) * p.ldw + cch * 8;
-    const int soff = srow * 128 + swz8(srow, cch) * 16;   // RSTRIDE is a multiple of 16: same swizzle key
-
-#define SRH_LOAD_A(dst, am, kt) { bool z_; const f16* s_ = a_src<AMODE>(p, am, (kt), z_); \
-        dst = *reinterpret_cast<const uint4*>(s_ + cch * 8);   /* always a valid address: load, then select */ \
-        if (AMODE != 0) { dst.x = z_ ? 0u : dst.x; dst.y = z_ ? 0u : dst.y; dst.z = z_ ? 0u : dst.z; dst.w = z_ ? 0u : dst.w; } }
-#define SRH_LOAD_TILE(kt) { SRH_LOAD_A(ra0, am0, kt) SRH_LOAD_A(ra1, am1, kt) SRH_LOAD_A(ra2, am2, kt) SRH_LOAD_A(ra3, am3, kt) \
-        rw0 = *reinterpret_cast<const uint4*>(wbase + (size_t)(kt) * BK); \
-        rw1 = *reinterpret_cast<const uint4*>(wbase + (size_t)(RSTRIDE) * p.ldw + (size_t)(kt) * BK); \
-        rw2 = *reinterpret_cast<const uint4*>(wbase + (size_t)(2 * RSTRIDE) * p.ldw + (size_t)(kt) * BK); \
-        rw3 = *reinterpret_cast<const uint4*>(wbase + (size_t)(3 * RSTRIDE) * p.ldw + (size_t)(kt) * BK); }
-#define SRH_STORE_TILE(stage) { char* sa_ = smem + (stage) * STAGE + soff; char* sw_ = sa_ + A_BYTES; \
-        *reinterpret_cast<uint4*>(sa_) = ra0; *reinterpret_cast<uint4*>(sw_) = rw0; \
-        *reinterpret_cast<uint4*>(sa_ + RSTRIDE * 128) = ra1; *reinterpret_cast<uint4*>(sw_ + RSTRIDE * 128) = rw1; \
-        *reinterpret_cast<uint4*>(sa_ + RSTRIDE * 256) = ra2; *reinterpret_cast<uint4*>(sw_ + RSTRIDE * 256) = rw2; \
-        *reinterpret_cast<uint4*>(sa_ + RSTRIDE * 384) = ra3; *reinterpret_cast<uint4*>(sw_ + RSTRIDE * 384) = rw3; }
-
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    SRH_LOAD_TILE(0)
-    SRH_STORE_TILE(0)
-    __syncthreads();
-
-    const int frow = lane & 31, fhalf = lane >> 5;
-    // fragment byte offsets inside a tile: row r, k-step ks -> r*128 + swz8(r, 2ks+half)*16; every row this
-    // lane reads is frow + 32*j, so the swizzle key ((row>>1)&7) is the lane's own.
-    const int fkey = (frow >> 1) & 7;
-    int foff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = frow * 128 + (((ks * 2 + fhalf) ^ fkey) << 4);
-    const int w_row0 = (wn * TN * 32) * 128, x_row0 = (wm * TM * 32) * 128;
-
-#define SRH_FRAG(fw, fx, ks) { \
-    _Pragma("unroll") for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const f16x8*>(sw + foff[ks] + 4096 * i); \
-    _Pragma("unroll") for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const f16x8*>(sa + foff[ks] + 4096 * j); }
-#define SRH_MMA(fw, fx) { \
-    _Pragma("unroll") for (int i = 0; i < TN; ++i) \
-    _Pragma("unroll") for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]); }
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        const int ktn = kt + 1 < nk ? kt + 1 : kt;    // last iteration re-loads its own tile (no branch)
-        SRH_LOAD_TILE(ktn)
-        const char* sa = smem + stage * STAGE + x_row0;
-        const char* sw = smem + stage * STAGE + A_BYTES + w_row0;
-        f16x8 fwA[TN], fxA[TM], fwB[TN], fxB[TM];
-        // Order pinned with sched_barrier: hipcc otherwise sinks the global loads below the MFMAs (to
-        // the ds_write that consumes them), exposing the full memory latency every k-tile, and collapses
-        // the fragment double-buffering.
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_FRAG(fwA, fxA, 0)
-        SRH_FRAG(fwB, fxB, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_MMA(fwA, fxA)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_FRAG(fwA, fxA, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_MMA(fwB, fxB)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_FRAG(fwB, fxB, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_MMA(fwA, fxA)
-        SRH_MMA(fwB, fxB)
-        __builtin_amdgcn_sched_barrier(0);
-        SRH_STORE_TILE(stage ^ 1)
-        __syncthreads();
-    }
-
-    epilogue<TN, TM>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
-}
-
-template <int AMODE, int WN, int WM, int TN, int TM>
-static int launch_cfg(const GemmParams& p, hipStream_t stream) {
-    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, THREADS = WN * WM * 64;
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_kernel<AMODE, WN, WM, TN, TM>;
-    static OncePerDevice opt_in;       // one per template instantiation
-    if (!opt_in.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess; }))
-        return -3;
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // Small-M layers: take 128x160 tiles (gemm_glds160_kernel) when more than one round of 128x128 tiles is one round of 128x160 tiles

@@ -187,8 +187,8 @@ int launch_layernorm(const NormParams& p, hipStream_t s) {
     if (p.slices) {      // the small-M models' pass after a split-K fc2 (api.hip): its own instantiations, the others stay as they were
         if (p.delta16 || p.delta16b || p.nslices < 1 || !p.slice_bias) return -2;
         switch (p.D) {
-            case 1024: launch_ln<16, 4, 2, 0, true>(p, s); break;
-            case 1280: launch_ln<20, 4, 2, 0, true>(p, s); break;
+            case 1024: launch_ln<16, 4, 1, 0, true>(p, s); break;
+            case 1280: launch_ln<20, 4, 1, 0, true>(p, s); break;
             default: return -2;
         }
         return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -200,8 +200,8 @@ int launch_layernorm(const NormParams& p, hipStream_t s) {
         // touched once per pass; keeping it out of L2 leaves qkv / K / V there for the attention kernels): +0.7 % tiles/s over <12, 4, 2>
         // with cached accesses, same box, alternating (profiles/r04_layernorm_nt.txt).  Bit-identical output.
         case 768:  launch_ln<12, 4, 1, 3>(p, s); break;
-        case 1024: launch_ln<16, 4, 2>(p, s); break;
-        case 1280: launch_ln<20, 4, 2>(p, s); break;
+        case 1024: launch_ln<16, 4, 1>(p, s); break;
+        case 1280: launch_ln<20, 4, 1>(p, s); break;
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -50,19 +50,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return fmaf(-a, e, fmaxf(x, 0.f));
 }
 
-// the same with a DEGREE-3 exponent polynomial (3 FMA + v_exp_f32 + max + FMA; max abs error 9.5e-5): what the generated z192 bodies use for
-// the MLP's hidden activation (tools/kgen/gemm_z192_gen.py GELU_FITS[3]) — for VALU-bound epilogues whose result is rounded to fp16 anyway
-// (the fused map_decoder: 58.7 M GELUs per 16 tiles).  Monotone, r grows without bound: finite for every input.
-__device__ __forceinline__ float gelu_fast3(float x) {
-    const float a = fabsf(x);
-    float r = 0.027115101429684235f;
-    r = fmaf(r, a, 0.49156223219618944f);
-    r = fmaf(r, a, 1.135889844701584f);
-    r = fmaf(r, a, 1.001923220905336f);
-    const float e = __builtin_amdgcn_exp2f(-r);
-    return fmaf(-a, e, fmaxf(x, 0.f));
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

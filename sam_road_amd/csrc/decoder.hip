@@ -27,8 +27,9 @@ namespace srh {
 // accumulator registers per column group are live.  A workgroup (NW waves) has sub1 = blockIdx & 3 fixed: its LDS holds that 64 KiB slice of
 // layer 0 plus all of layers 3 (64 KiB) and 5 (16 KiB), staged once by LDS-DMA; the last layer's 8 x 32 f32 weights sit in registers as an fp16 hi + lo
 // pair (two MFMAs keep their f32 value to 2^-22).  Per lane the last tile holds one 2-pixel x 2-class float4 of one output row.
-// GELU = gelu_fast3 (degree-3 exponent polynomial, common.hpp).  Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles) behind a serial
-// per-wave chain; HBM floor 8 MB in + 33.5 MB out.  Measured (profiles/r06_decoder_probe.txt): 36.6 us alone at B = 16, ~42 in the model.
+// GELU = gelu_fast (degree-5 exponent polynomial, common.hpp; the degree-3 one of the z192 bodies saved 2.5 us and cost 0.5e-4 of the 5e-4
+// mask-score bound in the randomised sweep: not taken).  Bound: VALU (58.7 M GELUs + 8.4 M sigmoids per 16 tiles) behind a serial
+// per-wave chain; HBM floor 8 MB in + 33.5 MB out.  Measured (profiles/r06_decoder_probe.txt): 39 us alone at B = 16, ~45 in the model.
 constexpr int DF_W0 = 65536, DF_W3 = 65536, DF_W5 = 16384, DF_PRM_BYTES = 3072, DF_LDS = DF_W0 + DF_W3 + DF_W5 + DF_PRM_BYTES;   // parameters: 738 floats, packed into 3 KiB (api.hip)
 // NCG column groups of 16 tokens per wave job x NW waves per workgroup: <2, 8> shares every fragment read between two column groups
 // (half the LDS traffic, 170 VGPRs: two waves per SIMD; measured 52 us in the model); <1, 16> — the one launched — has four waves per
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(prm + 128 + 16 * rt + 4 * g);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(prm + 256 + 16 * rt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a0[rt][cg][r] = gelu_fast3(a0[rt][cg][r] * rstd * ga[r] + be[r]);
+                for (int r = 0; r < 4; ++r) a0[rt][cg][r] = gelu_fast(a0[rt][cg][r] * rstd * ga[r] + be[r]);
             }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) x1[cg][kb] = df_pack8(a0[2 * kb][cg], a0[2 * kb + 1][cg]);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
                 for (int rt = 0; rt < 4; ++rt) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(prm + 384 + 16 * rt + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a3[rt][cg][r] = gelu_fast3(a3[rt][cg][r] + b[r]);
+                    for (int r = 0; r < 4; ++r) a3[rt][cg][r] = gelu_fast(a3[rt][cg][r] + b[r]);
                 }
                 x2[cg][0] = df_pack8(a3[0][cg], a3[1][cg]);
                 x2[cg][1] = df_pack8(a3[2][cg], a3[3][cg]);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(DF_WAVES * 64) void decode_fused_kernel(DecodeFused
 #pragma unroll
                 for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a5[rt][cg][r] = gelu_fast3(a5[rt][cg][r] + b[r]);
+                    for (int r = 0; r < 4; ++r) a5[rt][cg][r] = gelu_fast(a5[rt][cg][r] + b[r]);
             }
             // ---- layer 7 (32 -> 2 x 2 pixels x 2 classes) + sigmoid + scatter; rows 4 g + r: g = ky, r = kx * 2 + class
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised HIP-vs-oracle parity sweep (run on an MI355X): random batch sizes (incl. 1 and odd ones that leave GEMM row tails),
-random point counts per tile (incl. 1, ragged, all-invalid rows), every TOPONET_VERSION, ViT-B 256 / 512 tiles at depth 2 and a
+random point counts per tile (incl. 1, ragged, all-invalid rows), every TOPONET_VERSION, ViT-B 256 / 512 / 1024-px tiles at depth 2 and a
 small full infer_one_img with odd scene sizes / margins / batch sizes.  Prints one line per case and a summary; exit code 1 on any
 violation of the stated tolerances (tests/tolerances.py).   python tools/fuzz_parity.py [--cases 40] [--seed 0]"""
 import argparse
@@ -54,10 +54,13 @@ def main():
         sam = "vit_b"
         if c % 6 == 5:                                           # ViT-L / ViT-H widths (head dim 64 x 16 heads / 80 x 16 heads): 256 px tiles
             P, sam = 256, str(rng.choice(["vit_l", "vit_h"]))
+        elif c % 8 == 6:                                         # round 6: 1024-px tiles (toponet_vitb_1024.yaml: 25 windows, the 64 x 64 global window)
+            P = 1024
         cfg, oracle, net = pair(P, ver, gidx, sam)
-        if c % 4 != 3 or sam != "vit_b":
+        if c % 4 != 3 or sam != "vit_b" or P == 1024:
             # up to the shipped YAMLs' INFER_BATCH_SIZE = 64 (and one past it): B >= 8 (512 px) / 32 (256 px) takes the persistent q192 GEMMs
-            B = int(rng.choice([1, 2, 3, 5, 7, 16, 32, 33])) if P == 512 else int(rng.choice([1, 2, 3, 5, 9, 17, 32, 64, 65]))
+            B = (int(rng.choice([1, 2, 3, 5])) if P == 1024 else int(rng.choice([1, 2, 3, 5, 7, 16, 32, 33])) if P == 512
+                 else int(rng.choice([1, 2, 3, 5, 9, 17, 32, 64, 65])))
             npts = int(rng.choice([1, 2, 17, 40, 96]))
             rgb = synth_tiles(B, P, seed=int(rng.integers(1 << 30)))
             points, pairs, valid = synth_queries(B, npts, P, seed=int(rng.integers(1 << 30)))
